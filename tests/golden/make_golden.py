@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE itself (build container only).
+
+Needs oracle/_ref (python oracle/build_ref.py), i.e. /root/reference compiled in place with
+its own toolchain.  Fixtures are data only: seeded inputs + the reference's outputs.
+What cannot be generated from the reference here, and what stands in for it:
+  * index stream: UniformGenerator is a cdef class -> libstdc++ <random> called directly
+    (tests/golden/gen_stream.cpp), the very code the reference executes (cymf/math.pxd:31-39).
+  * WMF: cymf/wmf.pyx + linalg.pyx are unbuildable here (cblas.h) -> numpy restatement with
+    LAPACK dgesv (np.linalg.solve); marked unpinned=1 inside the file.
+  * Evaluator: cymf/evaluator.pyx does not compile under Cython 3 -> only cymf/metrics.pyx
+    (which builds) is pinned, on fixed 0/1 vectors.
+Run:  python tests/golden/make_golden.py
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+from scipy import sparse
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+
+from cymf_amd.synthetic import implicit_matrix  # noqa: E402
+
+from cymf.bpr import BPR  # noqa: E402  (the compiled reference)
+from cymf.glove import GloVe  # noqa: E402
+from cymf.relmf import RelMF  # noqa: E402
+from cymf import metrics as ref_metrics  # noqa: E402
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"{name}.npz  {os.path.getsize(path)/1024:.1f} kB")
+
+
+def stream_fixtures():
+    exe = os.path.join(ROOT, "oracle", "_ref", "gen_stream")
+    subprocess.check_call(["g++", "-O2", "-std=c++11", os.path.join(HERE, "gen_stream.cpp"), "-o", exe])
+    out = {}
+    for rng_range in (1682, 3706, 100000, 7, 943 * 1682, 2**32 - 1, 2**32, 2**32 + 12345, 5 * 2**32 + 3):
+        txt = subprocess.check_output([exe, "1234", str(rng_range), "4096"]).decode().split()
+        out[f"r{rng_range}"] = np.array(txt, dtype=np.int64)
+    txt = subprocess.check_output([exe, "99", "100000", "4096"]).decode().split()
+    out["seed99_r100000"] = np.array(txt, dtype=np.int64)
+    # a long stream so that Lemire rejections (p = 6.7e-4 at this range) are exercised
+    txt = subprocess.check_output([exe, "1234", str(3000000000), "20000"]).decode().split()
+    out["r3000000000"] = np.array(txt, dtype=np.int64)
+    save("index_stream", **out)
+
+
+def bpr_fixture(name, X, K, lr, wd, epochs_list, optimizers, rows=None):
+    out = dict(indptr=X.indptr.astype(np.int32), indices=X.indices.astype(np.int32),
+               shape=np.array(X.shape), K=K, lr=lr, wd=wd, epochs=np.array(epochs_list))
+    for opt in optimizers:
+        for ep in epochs_list:
+            m = BPR(K, lr, opt, wd)
+            m.fit(X, num_epochs=ep, num_threads=1, verbose=False)
+            W, H = np.asarray(m.W), np.asarray(m.H)
+            if rows is None:
+                out[f"W_{opt}_{ep}"], out[f"H_{opt}_{ep}"] = W, H
+            else:
+                out[f"W_{opt}_{ep}"], out[f"H_{opt}_{ep}"] = W[:rows], H[:rows]
+                out[f"Wcs_{opt}_{ep}"], out[f"Hcs_{opt}_{ep}"] = W.sum(axis=0), H.sum(axis=0)
+                out[f"Wn_{opt}_{ep}"], out[f"Hn_{opt}_{ep}"] = np.linalg.norm(W), np.linalg.norm(H)
+    save(name, **out)
+
+
+def main():
+    stream_fixtures()
+
+    # (ii) BPR: tiny dense-ish case (many skipped draws), full W/H
+    rng = np.random.default_rng(0)
+    U, I = 60, 80
+    r, c = rng.integers(0, U, 1300), rng.integers(0, I, 1300)
+    X = sparse.csr_matrix((np.ones(1300), (r, c)), shape=(U, I))
+    X.data[:] = 1
+    X.sort_indices()
+    bpr_fixture("bpr_60x80", X, 8, 0.05, 0.01, [1, 3], ["sgd", "adagrad", "adam"])
+
+    # ml-100k-shaped (C1), K=20: first 48 rows + column sums + norms
+    X = implicit_matrix(943, 1682, 44853, 100)
+    bpr_fixture("bpr_c1", X, 20, 0.01, 0.01, [1, 3], ["sgd", "adagrad", "adam"], rows=48)
+    # K=128 / K=64 variants on a smaller matrix (lane layouts of the kernels), sgd + adam
+    X = implicit_matrix(300, 500, 9000, 5)
+    bpr_fixture("bpr_300x500_k128", X, 128, 0.05, 0.01, [2], ["sgd", "adam"], rows=32)
+    bpr_fixture("bpr_300x500_k64", X, 64, 0.05, 0.01, [2], ["sgd", "adagrad"], rows=32)
+
+    # survey check value
+    rng = np.random.default_rng(0)
+    U, I = 943, 1682
+    r, c = rng.integers(0, U, 55000), rng.integers(0, I, 55000)
+    X = sparse.csr_matrix((np.ones(55000), (r, c)), shape=(U, I))
+    X.data[:] = 1
+    m = BPR(20, 0.01, "sgd", 0.01)
+    m.fit(X, num_epochs=6, num_threads=1, verbose=False)
+    save("bpr_survey_check", Wsum=m.W.sum(), Hsum=m.H.sum(), nnz=X.nnz)
+
+    # (v) GloVe K=16, 2 epochs (caller seeds numpy: GloVe.fit does not, glove.pyx:91-94)
+    V = 120
+    rng = np.random.default_rng(3)
+    r, c = rng.integers(0, V, 2500), rng.integers(0, V, 2500)
+    d = np.clip(rng.lognormal(0.5, 1.5, 2500), 0.1, 1e4)
+    Xg = sparse.csr_matrix((d, (r, c)), shape=(V, V))
+    Xg.sort_indices()
+    out = dict(indptr=Xg.indptr.astype(np.int32), indices=Xg.indices.astype(np.int32), data=Xg.data,
+               V=V, np_seed=77, lr=0.05, alpha=0.75, x_max=10.0)
+    for K in (16, 100):
+        np.random.seed(77)
+        g = GloVe(K, 0.05, 0.75, 10.0)
+        g.fit(Xg, 2, 1)
+        out[f"W_k{K}"], out[f"bias_k{K}"] = np.asarray(g.W), np.asarray(g.bias)
+    save("glove_120", **out)
+
+    # (vi) RelMF 30x40, 1 and 2 epochs
+    U, I, K = 30, 40, 5
+    rng = np.random.default_rng(4)
+    Xr = (rng.random((U, I)) < 0.1).astype(np.float64)
+    out = dict(X=Xr, K=K, lr=0.05, wd=0.01, clip=0.1)
+    for opt in ("sgd", "adagrad", "adam"):
+        for ep in (1, 2):
+            m = RelMF(K, 0.1, 0.05, opt, 0.01)
+            m.fit(Xr, num_epochs=ep, num_threads=1)
+            out[f"W_{opt}_{ep}"], out[f"H_{opt}_{ep}"] = np.asarray(m.W), np.asarray(m.H)
+    save("relmf_30x40", **out)
+
+    # (vii) metrics on fixed 0/1 vectors (cymf/metrics.pyx builds; the evaluator does not)
+    rng = np.random.default_rng(5)
+    ys = (rng.random((64, 105)) < 0.06).astype(np.int32)
+    ys[0] = 0
+    ys[1, 0] = 1
+    ks = np.array([1, 3, 5, 10])
+    dcg = np.array([[ref_metrics.dcg_at_k(y, int(k)) for k in ks] for y in ys])
+    rec = np.array([[ref_metrics.recall_at_k(y, int(k)) for k in ks] for y in ys])
+    ap = np.array([[ref_metrics.average_precision_at_k(y, int(k)) for k in ks] for y in ys])
+    save("metrics", y=ys, ks=ks, dcg=dcg, recall=rec, ap=ap)
+
+    # (iv) WMF -- UNPINNED by the reference (see module docstring): numpy/LAPACK restatement
+    X = implicit_matrix(200, 300, 5000, 6)
+    Xt = X.T.tocsr()
+    out = dict(indptr=X.indptr.astype(np.int32), indices=X.indices.astype(np.int32), shape=np.array(X.shape),
+               weight=10.0, wd=0.01, unpinned=1)
+
+    def half(ip, ix, Xf, Y, w, lam):
+        K = Y.shape[1]
+        A0 = Y.T @ Y + lam * np.eye(K)
+        for i in range(Xf.shape[0]):
+            s = ix[ip[i]:ip[i + 1]]
+            if len(s) == 0:
+                Xf[i] = 0
+                continue
+            Ys = Y[s]
+            Xf[i] = np.linalg.solve(A0 + (w - 1.0) * (Ys.T @ Ys), w * Ys.sum(axis=0))
+
+    for K in (8, 64):
+        np.random.seed(4321)
+        W = np.random.uniform(-0.1, 0.1, (200, K)) / K
+        H = np.random.uniform(-0.1, 0.1, (300, K)) / K
+        for _ in range(2):
+            half(X.indptr, X.indices, W, H, 10.0, 0.01)
+            half(Xt.indptr, Xt.indices, H, W, 10.0, 0.01)
+        out[f"W_k{K}"], out[f"H_k{K}"] = W, H
+    save("wmf_200x300_unpinned", **out)
+
+
+if __name__ == "__main__":
+    main()
