@@ -1,0 +1,130 @@
+"""ctypes binding of libcymf_hip.so (include/cymf_amd.h).  No CPU fallback: if the HIP
+library is missing or no gfx950 device is visible the compute calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcymf_hip.so")
+_lib = None
+
+OPT_IDS = {"sgd": 0, "adagrad": 1, "adam": 2}
+DTYPE_IDS = {"float32": 0, "f32": 0, "float64": 1, "f64": 1}
+MODE_IDS = {"exact": 0, "throughput": 1}
+UNIQUE_ID_BYTES = 128
+
+
+class CymfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcymf_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(f"{SO_PATH} is missing: build it with `python -m cymf_amd.build` "
+                          "(there is no CPU fallback for the MI355X kernels)")
+    L = C.CDLL(SO_PATH)
+    vp, i32, i64, u32, u64, f64, ci = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double, C.c_int
+    pp = C.POINTER(vp)
+    sig = {
+        "cymf_last_error": ([], C.c_char_p),
+        "cymf_version": ([], ci),
+        "cymf_device_count": ([], ci),
+        "cymf_device_name": ([ci, C.c_char_p, ci], ci),
+        "cymf_device_sync": ([ci], ci),
+        "cymf_rng_fill_uniform": ([ci, u32, u64, i64, i64, vp], ci),
+        "cymf_bpr_create": ([pp, i32, i32, i32, ci, f64, f64, u32, ci, ci, ci], ci),
+        "cymf_bpr_set_data": ([vp, vp, vp, i64, vp, vp, vp, i64], ci),
+        "cymf_bpr_set_steps_per_epoch": ([vp, i32], ci),
+        "cymf_bpr_upload": ([vp, vp, vp], ci),
+        "cymf_bpr_download": ([vp, vp, vp], ci),
+        "cymf_bpr_epochs": ([vp, i32, vp], ci),
+        "cymf_bpr_steps": ([vp, i32, vp], ci),
+        "cymf_bpr_sync": ([vp], ci),
+        "cymf_bpr_stats": ([vp, vp, vp], ci),
+        "cymf_bpr_set_profiling": ([vp, ci], ci),
+        "cymf_bpr_kernel_time": ([vp, vp, vp, vp], ci),
+        "cymf_bpr_last_negatives": ([vp, vp, i64], ci),
+        "cymf_bpr_destroy": ([vp], ci),
+        "cymf_comm_unique_id": ([vp], ci),
+        "cymf_comm_create": ([pp, vp, ci, ci, ci], ci),
+        "cymf_comm_destroy": ([vp], ci),
+        "cymf_comm_allreduce_f32": ([vp, vp, i64, ci], ci),
+        "cymf_bpr_attach_comm": ([vp, vp], ci),
+        "cymf_relmf_create": ([pp, i32, i32, i32, ci, f64, f64, f64, u32, ci, ci, ci], ci),
+        "cymf_relmf_set_data": ([vp, vp, vp], ci),
+        "cymf_relmf_upload": ([vp, vp, vp], ci),
+        "cymf_relmf_download": ([vp, vp, vp], ci),
+        "cymf_relmf_epochs": ([vp, i32, vp], ci),
+        "cymf_relmf_destroy": ([vp], ci),
+        "cymf_glove_create": ([pp, i32, i32, i32, f64, f64, f64, ci, ci, ci], ci),
+        "cymf_glove_set_data": ([vp, vp, vp, vp, i64], ci),
+        "cymf_glove_upload": ([vp, vp, vp, vp, vp], ci),
+        "cymf_glove_download": ([vp, vp, vp, vp, vp], ci),
+        "cymf_glove_epochs": ([vp, i32, vp], ci),
+        "cymf_glove_destroy": ([vp], ci),
+        "cymf_wmf_create": ([pp, i32, i32, i32, f64, f64, ci, ci], ci),
+        "cymf_wmf_set_data": ([vp, vp, vp, vp, vp], ci),
+        "cymf_wmf_upload": ([vp, vp, vp], ci),
+        "cymf_wmf_download": ([vp, vp, vp], ci),
+        "cymf_wmf_half_sweep": ([vp, ci], ci),
+        "cymf_wmf_epochs": ([vp, i32], ci),
+        "cymf_wmf_destroy": ([vp], ci),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = the .so does not export the header's symbol
+        fn.argtypes = args
+        fn.restype = res
+    L._signatures = sig
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().cymf_last_error()
+        raise CymfError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f64c(a):
+    a = np.asarray(a)
+    if a.dtype != np.float64 or not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+    return a
+
+
+def i32c(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def device_count():
+    try:
+        return int(lib().cymf_device_count())
+    except (ImportError, OSError):
+        return 0
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(lib().cymf_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+def device_sync(device=0):
+    check(lib().cymf_device_sync(device))
+
+
+def rng_fill_uniform(seed, rng_range, n, skip=0, device=0):
+    """Draws [skip, skip+n) of UniformGenerator(0, rng_range, seed) (cymf/math.pyx:12-18), generated on the GPU."""
+    out = np.empty(int(n), dtype=np.int64)
+    check(lib().cymf_rng_fill_uniform(device, int(seed), int(rng_range), int(n), int(skip), ptr(out)))
+    return out

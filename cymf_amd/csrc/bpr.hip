@@ -1,0 +1,1004 @@
+// bpr.hip -- BPR negative-sampling SGD on gfx950.
+// Replaces BPR._fit_bpr (cymf/bpr.pyx:117-190): epoch loop :160-171, BprModel.forward/backward
+// (cymf/model.pyx:47-87) and the optimizers (cymf/optimizer.pyx:40-160), fused per triplet.
+//
+// One wavefront owns one triplet (u, i, j): the K factors of a row are spread over the 64 lanes
+// (rows.h), the dot product is a DPP reduction, everything else is element-wise.
+//
+//   EXACT mode      : the reference's sequential order.  Two triplets commute iff their row sets
+//                     {W[u], H[i], H[j]} are disjoint, so level(l) = 1 + max level of the last
+//                     earlier triplet touching u, i or j gives conflict-free waves of work that are
+//                     equivalent to the serial chain; one launch per level.
+//   THROUGHPUT mode : HOGWILD (cymf/bpr.pyx:75).  Triplets are bucketed by positive item; a
+//                     wavefront walks 64 consecutive slots of the item-sorted order with the
+//                     positive item's row held in registers and flushed once per item run with a
+//                     float atomic add of its delta; W[u] and H[j] rows are gathered ahead and
+//                     written back in place.
+#include "store.h"
+
+#include <algorithm>
+
+namespace cymf {
+
+// =====================================================================================
+//                                        kernels
+// =====================================================================================
+namespace {
+
+template <typename T>
+struct BprDev {
+    T *W, *H;          // (U,K), (I,K)
+    T *W0, *W1;        // optimizer state for W (AdaGrad: acc; Adam: m, v)
+    T *H0, *H1;        // optimizer state for H
+    int K;
+    T wd;
+    OptParams<T> opt;
+};
+
+__device__ __forceinline__ float softplus_neg(float x) {   // -log(sigmoid(x)), overflow-free
+    return fmaxf(-x, 0.0f) + log1pf(__expf(-fabsf(x)));
+}
+__device__ __forceinline__ double softplus_neg(double x) { return fmax(-x, 0.0) + log1p(exp(-fabs(x))); }
+__device__ __forceinline__ float inv1pexp(float x) { return 1.0f / (1.0f + expf(x)); }
+__device__ __forceinline__ double inv1pexp(double x) { return 1.0 / (1.0 + exp(x)); }
+
+// forward (model.pyx:47-62) + backward (model.pyx:66-87) on rows already in registers.
+// Gradients of every component use the pre-update values (model.pyx:81-87).
+template <typename T, int R, bool PACKED, int OPT>
+__device__ __forceinline__ T bpr_update_rows(const BprDev<T> &d, Row<T, R, PACKED> &w, Row<T, R, PACKED> &hi,
+                                             Row<T, R, PACKED> &hj, Row<T, R, PACKED> *sw, Row<T, R, PACKED> *shi,
+                                             Row<T, R, PACKED> *shj) {
+    T px = 0, pl = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        px += w.v[r] * (hi.v[r] - hj.v[r]);
+        pl += w.v[r] * w.v[r] + hi.v[r] * hi.v[r] + hj.v[r] * hj.v[r];
+    }
+    const T x = wave_sum(px);
+    const T l2 = wave_sum(pl);
+    const T loss = softplus_neg(x) + d.wd * l2;
+    const T s = inv1pexp(x);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const T wv = w.v[r], iv = hi.v[r], jv = hj.v[r];
+        const T gw = -(s * (iv - jv) - d.wd * wv);
+        const T gi = -(s * wv - d.wd * iv);
+        const T gj = -(s * (-wv) - d.wd * jv);
+        T dummy = 0;
+        opt_update<T, OPT>(d.opt, w.v[r], OPT >= 1 ? sw[0].v[r] : dummy, OPT == 2 ? sw[1].v[r] : dummy, gw);
+        opt_update<T, OPT>(d.opt, hi.v[r], OPT >= 1 ? shi[0].v[r] : dummy, OPT == 2 ? shi[1].v[r] : dummy, gi);
+        opt_update<T, OPT>(d.opt, hj.v[r], OPT >= 1 ? shj[0].v[r] : dummy, OPT == 2 ? shj[1].v[r] : dummy, gj);
+    }
+    return loss;
+}
+
+// ---------------------------------------------------------------- EXACT: one level = independent triplets
+template <typename T, int R, bool PACKED, int OPT>
+__global__ __launch_bounds__(256) void bpr_level_kernel(BprDev<T> d, const int32_t *__restrict__ tu,
+                                                       const int32_t *__restrict__ ti,
+                                                       const int32_t *__restrict__ tj, int n,
+                                                       double *__restrict__ loss_acc) {
+    const int lane = lane_id();
+    const int t = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (t >= n) return;
+    const int K = d.K;
+    const int64_t ou = (int64_t)tu[t] * K, oi = (int64_t)ti[t] * K, oj = (int64_t)tj[t] * K;
+    constexpr int NS = opt_num_states(OPT);
+    Row<T, R, PACKED> w, hi, hj, sw[NS ? NS : 1], shi[NS ? NS : 1], shj[NS ? NS : 1];
+    w.load(d.W + ou, K, lane);
+    hi.load(d.H + oi, K, lane);
+    hj.load(d.H + oj, K, lane);
+    if constexpr (NS >= 1) { sw[0].load(d.W0 + ou, K, lane); shi[0].load(d.H0 + oi, K, lane); shj[0].load(d.H0 + oj, K, lane); }
+    if constexpr (NS >= 2) { sw[1].load(d.W1 + ou, K, lane); shi[1].load(d.H1 + oi, K, lane); shj[1].load(d.H1 + oj, K, lane); }
+    const T loss = bpr_update_rows<T, R, PACKED, OPT>(d, w, hi, hj, sw, shi, shj);
+    w.store(d.W + ou, K, lane);
+    hi.store(d.H + oi, K, lane);
+    hj.store(d.H + oj, K, lane);
+    if constexpr (NS >= 1) { sw[0].store(d.W0 + ou, K, lane); shi[0].store(d.H0 + oi, K, lane); shj[0].store(d.H0 + oj, K, lane); }
+    if constexpr (NS >= 2) { sw[1].store(d.W1 + ou, K, lane); shi[1].store(d.H1 + oi, K, lane); shj[1].store(d.H1 + oj, K, lane); }
+    if (lane == 0) atomicAdd(loss_acc, (double)loss);
+}
+
+// ---------------------------------------------------------------- THROUGHPUT: resolve negatives of a slot range
+// slot t: triplet (slot_user[t], slot_item[t]) at global stream position slot_pos[t];
+// negative = draws[pos]; skipped (-1) when it is one of the user's positives (bpr.pyx:165-167).
+__global__ __launch_bounds__(256) void bpr_sample_kernel(const int32_t *__restrict__ slot_user,
+                                                        const uint32_t *__restrict__ slot_pos,
+                                                        const uint32_t *__restrict__ draws,
+                                                        const int32_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices,
+                                                        int32_t *__restrict__ slot_neg, int64_t n,
+                                                        unsigned long long *__restrict__ skipped) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned int my_skips = 0;
+    for (; t < n; t += stride) {
+        const int32_t u = slot_user[t];
+        const int32_t j = (int32_t)draws[slot_pos[t]];
+        int32_t lo = indptr[u], hi = indptr[u + 1];
+        bool found = false;
+        while (lo < hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            const int32_t v = indices[mid];
+            if (v == j) { found = true; break; }
+            if (v < j) lo = mid + 1; else hi = mid;
+        }
+        slot_neg[t] = found ? -1 : j;
+        my_skips += found ? 1u : 0u;
+    }
+    // wave-level count, one atomic per wave
+    unsigned long long m = 0;
+    for (int off = 32; off > 0; off >>= 1) my_skips += __shfl_xor(my_skips, off, 64);
+    m = my_skips;
+    if (lane_id() == 0 && m) atomicAdd(skipped, m);
+}
+
+// original-order view of the resolved negatives (test hook)
+__global__ void bpr_unsort_neg_kernel(const int32_t *__restrict__ slot_neg, const uint32_t *__restrict__ slot_local,
+                                      int32_t *__restrict__ out, int64_t n) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n; t += stride) out[slot_local[t]] = slot_neg[t];
+}
+
+// ---------------------------------------------------------------- THROUGHPUT: the step kernel
+// HOGWILD with bounded staleness.  The step's slots are sorted by positive item; wavefront w walks
+// its own CONTIGUOUS range of 64-slot chunks (blocked distribution), so the waves that are live at
+// one moment work on items spread over the whole popularity range and only ~n_waves * f_i of them
+// share a hot item i (f_i = its share of the triplets).
+//   H[i] (positive item) : held in registers across the item run; every 64 slots the wave adds its
+//        delta with a RETURNING float atomic and continues from (value found + delta): one coherent
+//        exchange point per chunk, no lost update however many waves share the item.
+//   H[j] (negative item) : gathered PF triplets ahead, its delta added with a float atomic: H is only
+//        ever modified at the memory side, so a stale L2/L1 copy can delay an update but never undo one.
+//   W[u] (user)          : gathered PF triplets ahead, written back in place (a user's triplets are
+//        spread over the item-sorted order; two waves rarely hold the same user at once).
+// Lane t of a chunk holds slot t's (user, item, negative); the walk itself is wave-uniform.
+template <typename RowT, int R>
+__device__ __forceinline__ void atomic_add_row(float *__restrict__ dst, const RowT &a, const RowT &b, int K, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = RowT::kof(lane, r);
+        if (k < K) atomicAdd(dst + k, a.v[r] - b.v[r]);      // no-return global_atomic_add_f32
+    }
+}
+
+// dst += (cur - base); cur = base = value found at the memory side + own delta
+template <typename RowT, int R>
+__device__ __forceinline__ void exchange_row(float *__restrict__ dst, RowT &cur, RowT &base, int K, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = RowT::kof(lane, r);
+        if (k < K) {
+            const float dlt = cur.v[r] - base.v[r];
+            const float found = atomicAdd(dst + k, dlt);    // returning form
+            cur.v[r] = found + dlt;
+            base.v[r] = cur.v[r];
+        }
+    }
+}
+
+template <int R, bool PACKED, int OPT, int PF>
+__global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const int32_t *__restrict__ slot_user,
+                                                      const int32_t *__restrict__ slot_item,
+                                                      const int32_t *__restrict__ slot_neg, int64_t slot_begin,
+                                                      int64_t slot_end, int64_t chunks_per_wave, int xcd_stride,
+                                                      double *__restrict__ loss_acc,
+                                                      unsigned long long *__restrict__ performed_acc) {
+    using RowT = Row<float, R, PACKED>;
+    constexpr int NS = opt_num_states(OPT);
+    constexpr int NSA = NS ? NS : 1;
+    const int lane = lane_id();
+    const int K = d.K;
+    const int64_t n_chunks = (slot_end - slot_begin + 63) >> 6;
+    if (blockIdx.x % xcd_stride) return;   // diagnostic: xcd_stride 8 keeps every active block on one XCD
+    const int64_t wave = ((int64_t)(blockIdx.x / xcd_stride) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t c_begin = wave * chunks_per_wave;
+    const int64_t c_end = c_begin + chunks_per_wave < n_chunks ? c_begin + chunks_per_wave : n_chunks;
+    float loss_sum = 0.0f;
+    unsigned int n_done = 0;
+    float *const Hs[2] = {d.H0, d.H1};
+
+    int cur_item = -1;
+    RowT hi, hi0, shi[NSA], shi0[NSA];
+
+    for (int64_t c = c_begin; c < c_end; ++c) {
+        const int64_t my = slot_begin + (c << 6) + lane;
+        const bool in = my < slot_end;
+        const int32_t u_l = in ? slot_user[my] : 0;
+        const int32_t i_l = in ? slot_item[my] : -1;
+        const int32_t j_l = in ? slot_neg[my] : -1;
+        unsigned long long pend = __ballot(j_l >= 0);     // performed slots whose rows are not yet requested
+        if (pend == 0) continue;
+        n_done += (unsigned int)__popcll(pend);
+
+        // ring of PF prefetched (W[u], H[j]) row pairs
+        RowT wq[PF], jq[PF], swq[PF][NSA], sjq[PF][NSA];
+        int uq[PF], jjq[PF], iq[PF];
+        int filled = 0;
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            uq[p] = jjq[p] = iq[p] = -1;
+            if (pend) {
+                const int t = __builtin_ctzll(pend);
+                pend &= pend - 1;
+                uq[p] = bcast_lane(u_l, t);
+                jjq[p] = bcast_lane(j_l, t);
+                iq[p] = bcast_lane(i_l, t);
+                wq[p].load(d.W + (int64_t)uq[p] * K, K, lane);
+                jq[p].load(d.H + (int64_t)jjq[p] * K, K, lane);
+                if constexpr (NS >= 1) { swq[p][0].load(d.W0 + (int64_t)uq[p] * K, K, lane); sjq[p][0].load(d.H0 + (int64_t)jjq[p] * K, K, lane); }
+                if constexpr (NS >= 2) { swq[p][1].load(d.W1 + (int64_t)uq[p] * K, K, lane); sjq[p][1].load(d.H1 + (int64_t)jjq[p] * K, K, lane); }
+                ++filled;
+            }
+        }
+        while (filled > 0) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                if (uq[p] < 0) continue;   // wave-uniform
+                const int u = uq[p], j = jjq[p], item = iq[p];
+                if (item != cur_item) {
+                    if (cur_item >= 0) {   // the finished item run: H[i] += (hi - hi0)
+                        atomic_add_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) atomic_add_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+                    }
+                    cur_item = item;
+                    hi.load(d.H + (int64_t)item * K, K, lane);
+                    hi0 = hi;
+                    if constexpr (NS >= 1) { shi[0].load(d.H0 + (int64_t)item * K, K, lane); shi0[0] = shi[0]; }
+                    if constexpr (NS >= 2) { shi[1].load(d.H1 + (int64_t)item * K, K, lane); shi0[1] = shi[1]; }
+                }
+                RowT w = wq[p], hj = jq[p];
+                RowT sw[NSA], shj[NSA];
+                if constexpr (NS >= 1) { sw[0] = swq[p][0]; shj[0] = sjq[p][0]; }
+                if constexpr (NS >= 2) { sw[1] = swq[p][1]; shj[1] = sjq[p][1]; }
+                loss_sum += bpr_update_rows<float, R, PACKED, OPT>(d, w, hi, hj, sw, shi, shj);
+                w.store(d.W + (int64_t)u * K, K, lane);
+                atomic_add_row<RowT, R>(d.H + (int64_t)j * K, hj, jq[p], K, lane);
+                if constexpr (NS >= 1) { sw[0].store(d.W0 + (int64_t)u * K, K, lane); atomic_add_row<RowT, R>(d.H0 + (int64_t)j * K, shj[0], sjq[p][0], K, lane); }
+                if constexpr (NS >= 2) { sw[1].store(d.W1 + (int64_t)u * K, K, lane); atomic_add_row<RowT, R>(d.H1 + (int64_t)j * K, shj[1], sjq[p][1], K, lane); }
+                --filled;
+                uq[p] = -1;
+                if (pend) {   // refill this ring position
+                    const int t = __builtin_ctzll(pend);
+                    pend &= pend - 1;
+                    uq[p] = bcast_lane(u_l, t);
+                    jjq[p] = bcast_lane(j_l, t);
+                    iq[p] = bcast_lane(i_l, t);
+                    wq[p].load(d.W + (int64_t)uq[p] * K, K, lane);
+                    jq[p].load(d.H + (int64_t)jjq[p] * K, K, lane);
+                    if constexpr (NS >= 1) { swq[p][0].load(d.W0 + (int64_t)uq[p] * K, K, lane); sjq[p][0].load(d.H0 + (int64_t)jjq[p] * K, K, lane); }
+                    if constexpr (NS >= 2) { swq[p][1].load(d.W1 + (int64_t)uq[p] * K, K, lane); sjq[p][1].load(d.H1 + (int64_t)jjq[p] * K, K, lane); }
+                    ++filled;
+                }
+            }
+        }
+        // chunk boundary: exchange the open item's progress with the other waves that share it
+        if (cur_item >= 0 && c + 1 < c_end) {
+            exchange_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) exchange_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+        }
+    }
+    if (cur_item >= 0) {
+        atomic_add_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) atomic_add_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+    }
+    if (lane == 0 && n_done) {
+        atomicAdd(loss_acc, (double)loss_sum);
+        atomicAdd(performed_acc, (unsigned long long)n_done);
+    }
+}
+
+// ---------------------------------------------------------------- small element-wise helpers
+template <typename T>
+__global__ void fill_kernel(T *p, T v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+template <typename T>
+__global__ void cast_from_f64_kernel(const double *__restrict__ in, T *__restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (T)in[i];
+}
+
+template <typename T>
+__global__ void cast_to_f64_kernel(const T *__restrict__ in, double *__restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = (double)in[i];
+}
+
+// multi-GPU: delta = H - snap   /   H = snap = snap + summed delta
+__global__ void delta_kernel(const float *__restrict__ H, const float *__restrict__ snap, float *__restrict__ delta, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) delta[i] = H[i] - snap[i];
+}
+__global__ void apply_delta_kernel(float *__restrict__ H, float *__restrict__ snap, const float *__restrict__ delta, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float v = snap[i] + delta[i];
+        H[i] = v;
+        snap[i] = v;
+    }
+}
+
+inline int ew_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+// =====================================================================================
+//                                  typed device storage
+// =====================================================================================
+template <typename T>
+int upload_f64(DevBuf<T> &dst, const double *src, size_t n, hipStream_t s) {
+    CYMF_TRY(dst.alloc(n));
+    if constexpr (sizeof(T) == sizeof(double)) {
+        CYMF_HIP(hipMemcpyAsync(dst.p, src, n * sizeof(double), hipMemcpyHostToDevice, s));
+    } else {
+        DevBuf<double> tmp;
+        CYMF_TRY(tmp.alloc(n));
+        CYMF_HIP(hipMemcpyAsync(tmp.p, src, n * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(cast_from_f64_kernel<T>, dim3(ew_blocks((int64_t)n)), dim3(256), 0, s, tmp.p, dst.p, (int64_t)n);
+        CYMF_HIP(hipGetLastError());
+        CYMF_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+template <typename T>
+int download_f64(const DevBuf<T> &src, double *dst, size_t n, hipStream_t s) {
+    if constexpr (sizeof(T) == sizeof(double)) {
+        CYMF_HIP(hipMemcpyAsync(dst, src.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        CYMF_HIP(hipStreamSynchronize(s));
+    } else {
+        DevBuf<double> tmp;
+        CYMF_TRY(tmp.alloc(n));
+        hipLaunchKernelGGL(cast_to_f64_kernel<T>, dim3(ew_blocks((int64_t)n)), dim3(256), 0, s, src.p, tmp.p, (int64_t)n);
+        CYMF_HIP(hipGetLastError());
+        CYMF_HIP(hipMemcpyAsync(dst, tmp.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        CYMF_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+template int upload_f64<float>(DevBuf<float> &, const double *, size_t, hipStream_t);
+template int upload_f64<double>(DevBuf<double> &, const double *, size_t, hipStream_t);
+template int download_f64<float>(const DevBuf<float> &, double *, size_t, hipStream_t);
+template int download_f64<double>(const DevBuf<double> &, double *, size_t, hipStream_t);
+
+template <typename T>
+int fill_dev(DevBuf<T> &b, size_t n, T v, hipStream_t s) {
+    CYMF_TRY(b.alloc(n));
+    hipLaunchKernelGGL(fill_kernel<T>, dim3(ew_blocks((int64_t)n)), dim3(256), 0, s, b.p, v, (int64_t)n);
+    CYMF_HIP(hipGetLastError());
+    return 0;
+}
+template int fill_dev<float>(DevBuf<float> &, size_t, float, hipStream_t);
+template int fill_dev<double>(DevBuf<double> &, size_t, double, hipStream_t);
+
+// =====================================================================================
+//                                       the trainer
+// =====================================================================================
+template <typename T>
+struct BprStore {
+    DevBuf<T> W, H, W0, W1, H0, H1;
+    BprDev<T> view(int K, double wd, double lr) {
+        BprDev<T> d;
+        d.W = W.p; d.H = H.p; d.W0 = W0.p; d.W1 = W1.p; d.H0 = H0.p; d.H1 = H1.p;
+        d.K = K; d.wd = (T)wd; d.opt = make_opt_params<T>(lr);
+        return d;
+    }
+};
+
+}  // namespace cymf
+
+using namespace cymf;
+
+struct cymf_bpr {
+    int32_t U = 0, I = 0, K = 0;
+    int opt = 0, dtype = 0, mode = 0, device = 0;
+    double lr = 0, wd = 0;
+    uint32_t seed = 1234;
+    hipStream_t stream = nullptr, rng_stream = nullptr;
+    BprStore<float> f32;
+    BprStore<double> f64;
+    bool have_params = false, have_data = false;
+
+    // data
+    int64_t N = 0, N_global = 0;
+    std::vector<int32_t> h_users, h_pos_items, h_indptr, h_indices;
+    std::vector<uint32_t> h_gpos;
+    DevBuf<int32_t> d_indptr, d_indices;
+
+    // stream of negatives
+    DeviceRng rng;
+    bool rng_ready = false;
+    DevBuf<uint32_t> d_draws[2];
+    hipEvent_t ev_gen[2] = {nullptr, nullptr}, ev_sampled[2] = {nullptr, nullptr};
+    int64_t epochs_generated = 0;   // draws of epochs [0, epochs_generated) have been requested
+    int64_t epoch_cursor = 0;       // next epoch to train
+    int32_t step_cursor = 0;        // next step inside epoch_cursor (throughput)
+    bool epoch_sampled = false;     // slot_neg holds epoch_cursor's negatives
+
+    // exact mode scratch
+    std::vector<uint32_t> h_draws;
+    std::vector<int32_t> h_last_neg;
+    DevBuf<int32_t> d_tu, d_ti, d_tj;
+
+    // throughput mode
+    int32_t steps_per_epoch = 1;
+    int32_t max_waves = 256 * 8;          // hardware side: 8 wavefronts per CU
+    int32_t rows_per_inflight = 8;        // staleness bound: table rows per row in flight
+    int32_t xcd_stride = 1;               // diagnostic (CYMF_BPR_XCD_STRIDE=8: all active blocks on one XCD)
+    std::vector<int64_t> step_off;           // slot offsets, steps_per_epoch+1
+    DevBuf<int32_t> d_slot_user, d_slot_item, d_slot_neg;
+    DevBuf<uint32_t> d_slot_pos, d_slot_local;
+    DevBuf<unsigned long long> d_skipped, d_performed;
+    int64_t slots_done = 0;              // slots walked by the step kernels since create
+    DevBuf<int32_t> d_unsorted_neg;
+
+    DevBuf<double> d_loss;
+    int64_t performed = 0, skipped = 0;
+
+    // multi-GPU
+    cymf_comm *comm = nullptr;
+    DevBuf<float> d_snap, d_delta;
+
+    // profiling of the dominant kernel
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms = 0;
+    int64_t prof_launches = 0, prof_units = 0;
+};
+
+namespace cymf {
+int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s);   // comm.hip
+int comm_world(cymf_comm *c);
+}
+
+namespace {
+
+int layout_R(int K) { return (K + 63) / 64; }
+bool layout_packed(int K) { return K == 128 || K == 256; }
+
+#define CYMF_DISPATCH_LAYOUT(K, CALL)                                      \
+    do {                                                                   \
+        const int R__ = layout_R(K);                                       \
+        if (R__ == 1) { CALL(1, false); }                                  \
+        else if (R__ == 2) { if (layout_packed(K)) { CALL(2, true); } else { CALL(2, false); } } \
+        else if (R__ == 3) { CALL(3, false); }                             \
+        else { if (layout_packed(K)) { CALL(4, true); } else { CALL(4, false); } } \
+    } while (0)
+
+template <typename T, int R, bool PACKED>
+void launch_level_opt(int opt, const BprDev<T> &d, const int32_t *tu, const int32_t *ti, const int32_t *tj, int n,
+                      double *loss, hipStream_t s) {
+    dim3 grid((n + 3) / 4), block(256);
+    switch (opt) {
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((bpr_level_kernel<T, R, PACKED, CYMF_OPT_SGD>), grid, block, 0, s, d, tu, ti, tj, n, loss); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((bpr_level_kernel<T, R, PACKED, CYMF_OPT_ADAGRAD>), grid, block, 0, s, d, tu, ti, tj, n, loss); break;
+    default: hipLaunchKernelGGL((bpr_level_kernel<T, R, PACKED, CYMF_OPT_ADAM>), grid, block, 0, s, d, tu, ti, tj, n, loss); break;
+    }
+}
+
+template <typename T>
+void launch_level(int K, int opt, const BprDev<T> &d, const int32_t *tu, const int32_t *ti, const int32_t *tj, int n,
+                  double *loss, hipStream_t s) {
+#define CALL_(R_, P_) launch_level_opt<T, R_, P_>(opt, d, tu, ti, tj, n, loss, s)
+    CYMF_DISPATCH_LAYOUT(K, CALL_);
+#undef CALL_
+}
+
+constexpr int STEP_PF = 8;
+
+template <int R, bool PACKED>
+void launch_step_opt(int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn,
+                     int64_t b, int64_t e, int64_t cpw, int xs, double *loss, unsigned long long *perf, int grid_blocks, hipStream_t s) {
+    dim3 grid(grid_blocks * xs), block(256);
+    switch (opt) {
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_SGD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, loss, perf); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, loss, perf); break;
+    default: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAM, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, loss, perf); break;
+    }
+}
+
+void launch_step(int K, int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn,
+                 int64_t b, int64_t e, int64_t cpw, int xs, double *loss, unsigned long long *perf, int grid_blocks, hipStream_t s) {
+#define CALL_(R_, P_) launch_step_opt<R_, P_>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s)
+    CYMF_DISPATCH_LAYOUT(K, CALL_);
+#undef CALL_
+}
+
+bool csr_has(const std::vector<int32_t> &indptr, const std::vector<int32_t> &indices, int32_t u, int32_t item) {
+    const int32_t *b = indices.data() + indptr[u], *e = indices.data() + indptr[u + 1];
+    return std::binary_search(b, e, item);
+}
+
+// ---- negatives of epoch `e` into d_draws[e & 1]; generated in stream order on rng_stream
+int request_epoch_draws(cymf_bpr *h, int64_t e) {
+    while (h->epochs_generated <= e) {
+        const int64_t g = h->epochs_generated;
+        const int b = (int)(g & 1);
+        CYMF_TRY(h->d_draws[b].alloc((size_t)h->N_global));
+        // buffer b was last read by the sampling of epoch g-2
+        if (g >= 2) CYMF_HIP(hipStreamWaitEvent(h->rng_stream, h->ev_sampled[b], 0));
+        CYMF_TRY(h->rng.generate(0, h->N_global, h->d_draws[b].p, h->rng_stream));
+        CYMF_HIP(hipEventRecord(h->ev_gen[b], h->rng_stream));
+        h->epochs_generated++;
+    }
+    return 0;
+}
+
+int fetch_loss(cymf_bpr *h, double *out) {
+    CYMF_HIP(hipMemcpyAsync(out, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// =============================== EXACT epoch ===============================
+template <typename T>
+int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
+    const int64_t e = h->epoch_cursor;
+    const int b = (int)(e & 1);
+    CYMF_TRY(request_epoch_draws(h, e));
+    h->h_draws.resize((size_t)h->N_global);
+    CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_gen[b], 0));
+    CYMF_HIP(hipMemcpyAsync(h->h_draws.data(), h->d_draws[b].p, (size_t)h->N_global * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->stream));
+
+    // level scheduling (host): level(l) = 1 + max(level of the last earlier triplet touching u, i or j)
+    const int64_t N = h->N;
+    std::vector<int32_t> lastW((size_t)h->U, 0), lastH((size_t)h->I, 0), level((size_t)N, 0);
+    h->h_last_neg.assign((size_t)N, -1);
+    int32_t n_levels = 0;
+    int64_t n_skipped = 0;
+    for (int64_t l = 0; l < N; ++l) {
+        const int32_t u = h->h_users[l], i = h->h_pos_items[l];
+        const int32_t j = (int32_t)h->h_draws[h->h_gpos[l]];
+        if (csr_has(h->h_indptr, h->h_indices, u, j)) { ++n_skipped; continue; }   // bpr.pyx:166-167
+        h->h_last_neg[l] = j;
+        int32_t lv = std::max(lastW[u], std::max(lastH[i], lastH[j])) + 1;
+        lastW[u] = lastH[i] = lastH[j] = lv;
+        level[l] = lv;
+        n_levels = std::max(n_levels, lv);
+    }
+    std::vector<int64_t> off((size_t)n_levels + 2, 0);
+    for (int64_t l = 0; l < N; ++l) if (level[l]) off[level[l] + 1]++;
+    for (int32_t v = 1; v <= n_levels + 1; ++v) off[v] += off[v - 1];
+    const int64_t n_perf = N - n_skipped;
+    std::vector<int32_t> tu((size_t)n_perf), ti((size_t)n_perf), tj((size_t)n_perf);
+    {
+        std::vector<int64_t> cur(off.begin(), off.end());
+        for (int64_t l = 0; l < N; ++l) {
+            if (!level[l]) continue;
+            const int64_t p = cur[level[l]]++;
+            tu[p] = h->h_users[l]; ti[p] = h->h_pos_items[l]; tj[p] = h->h_last_neg[l];
+        }
+    }
+    CYMF_TRY(h->d_tu.upload(tu.data(), tu.size(), h->stream));
+    CYMF_TRY(h->d_ti.upload(ti.data(), ti.size(), h->stream));
+    CYMF_TRY(h->d_tj.upload(tj.data(), tj.size(), h->stream));
+    CYMF_TRY(h->d_loss.zero(h->stream));
+    BprDev<T> d = st.view(h->K, h->wd, h->lr);
+    hipEvent_t p0 = nullptr, p1 = nullptr;
+    if (h->profiling) {
+        CYMF_HIP(hipEventCreate(&p0)); CYMF_HIP(hipEventCreate(&p1));
+        CYMF_HIP(hipEventRecord(p0, h->stream));
+    }
+    for (int32_t lv = 1; lv <= n_levels; ++lv) {
+        const int64_t b0 = off[lv], n = off[lv + 1] - off[lv];
+        if (n <= 0) continue;
+        launch_level<T>(h->K, h->opt, d, h->d_tu.p + b0, h->d_ti.p + b0, h->d_tj.p + b0, (int)n, h->d_loss.p, h->stream);
+    }
+    CYMF_HIP(hipGetLastError());
+    if (h->profiling) {
+        CYMF_HIP(hipEventRecord(p1, h->stream));
+        h->prof_events.emplace_back(p0, p1);
+        h->prof_launches += n_levels;
+        h->prof_units += n_perf;
+    }
+    double loss = 0;
+    CYMF_TRY(fetch_loss(h, &loss));
+    if (loss_out) *loss_out = N ? loss / (double)N : 0.0;   // bpr.pyx:171
+    h->performed += n_perf;
+    h->skipped += n_skipped;
+    h->epoch_cursor++;
+    return 0;
+}
+
+// =============================== THROUGHPUT steps ===============================
+int ensure_epoch_sampled(cymf_bpr *h) {
+    if (h->epoch_sampled) return 0;
+    const int64_t e = h->epoch_cursor;
+    const int b = (int)(e & 1);
+    CYMF_TRY(request_epoch_draws(h, e));
+    CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_gen[b], 0));
+    if (h->N > 0) {
+        int blocks = (int)std::min<int64_t>((h->N + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(bpr_sample_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_slot_user.p, h->d_slot_pos.p,
+                           h->d_draws[b].p, h->d_indptr.p, h->d_indices.p, h->d_slot_neg.p, h->N, h->d_skipped.p);
+        CYMF_HIP(hipGetLastError());
+    }
+    CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->stream));
+    h->epoch_sampled = true;
+    // run the generator one epoch ahead, concurrently with this epoch's steps
+    CYMF_TRY(request_epoch_draws(h, e + 1));
+    return 0;
+}
+
+int run_one_step(cymf_bpr *h) {
+    CYMF_TRY(ensure_epoch_sampled(h));
+    const int32_t s = h->step_cursor;
+    const int64_t b = h->step_off[s], e = h->step_off[s + 1];
+    BprDev<float> d = h->f32.view(h->K, h->wd, h->lr);
+    if (e > b) {
+        const int64_t chunks = (e - b + 63) / 64;
+        // Number of wavefronts = bounded staleness (see the kernel header): at most `max_waves` from
+        // the hardware side, and few enough that the rows in flight (waves * PF) stay a small
+        // fraction of the smaller table, so that two waves rarely hold the same row at once.
+        int64_t waves = std::min<int64_t>(chunks, h->max_waves);
+        const int64_t by_rows = std::max<int64_t>(1, std::min(h->U, h->I) / ((int64_t)h->rows_per_inflight * STEP_PF));
+        waves = std::max<int64_t>(1, std::min(waves, by_rows));
+        const int64_t cpw = (chunks + waves - 1) / waves;
+        waves = (chunks + cpw - 1) / cpw;
+        const int grid = (int)((waves + 3) / 4);
+        hipEvent_t p0 = nullptr, p1 = nullptr;
+        if (h->profiling) {
+            if (h->prof_pool.size() >= 2) {
+                p0 = h->prof_pool.back(); h->prof_pool.pop_back();
+                p1 = h->prof_pool.back(); h->prof_pool.pop_back();
+            } else {
+                CYMF_HIP(hipEventCreate(&p0)); CYMF_HIP(hipEventCreate(&p1));
+            }
+            CYMF_HIP(hipEventRecord(p0, h->stream));
+        }
+        launch_step(h->K, h->opt, d, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg.p, b, e, cpw, h->xcd_stride, h->d_loss.p, h->d_performed.p, grid, h->stream);
+        CYMF_HIP(hipGetLastError());
+        if (h->profiling) {
+            CYMF_HIP(hipEventRecord(p1, h->stream));
+            h->prof_events.emplace_back(p0, p1);
+            h->prof_launches += 1;
+            h->prof_units += e - b;
+        }
+        h->slots_done += e - b;
+    }
+    if (h->comm) {   // sum of the ranks' item-factor deltas
+        const int64_t n = (int64_t)h->I * h->K;
+        hipLaunchKernelGGL(delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_delta.p, n);
+        CYMF_HIP(hipGetLastError());
+        CYMF_TRY(comm_allreduce_sum_f32(h->comm, h->d_delta.p, n, h->stream));
+        hipLaunchKernelGGL(apply_delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_delta.p, n);
+        CYMF_HIP(hipGetLastError());
+    }
+    h->step_cursor++;
+    if (h->step_cursor >= h->steps_per_epoch) {
+        h->step_cursor = 0;
+        h->epoch_cursor++;
+        h->epoch_sampled = false;
+    }
+    return 0;
+}
+
+int collect_skips(cymf_bpr *h) {   // after a stream sync: performed comes from the step kernels
+    unsigned long long p = 0;
+    CYMF_HIP(hipMemcpyAsync(&p, h->d_performed.p, sizeof p, hipMemcpyDeviceToHost, h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    h->performed = (int64_t)p;
+    h->skipped = h->slots_done - h->performed;
+    return 0;
+}
+
+int build_throughput_layout(cymf_bpr *h) {
+    const int64_t N = h->N;
+    const int32_t S = h->steps_per_epoch;
+    // step of a triplet = window of the GLOBAL order it falls into; slots sorted by (step, item)
+    auto step_of = [&](int64_t l) -> int32_t {
+        return (int32_t)(((__int128)h->h_gpos[l] * S) / (h->N_global > 0 ? h->N_global : 1));
+    };
+    std::vector<int64_t> cnt((size_t)h->I + 1, 0);
+    for (int64_t l = 0; l < N; ++l) cnt[(size_t)h->h_pos_items[l] + 1]++;
+    for (int32_t i = 0; i < h->I; ++i) cnt[i + 1] += cnt[i];
+    std::vector<uint32_t> by_item((size_t)N);
+    for (int64_t l = 0; l < N; ++l) by_item[(size_t)cnt[h->h_pos_items[l]]++] = (uint32_t)l;
+    h->step_off.assign((size_t)S + 1, 0);
+    for (int64_t l = 0; l < N; ++l) h->step_off[(size_t)step_of(l) + 1]++;
+    for (int32_t s = 0; s < S; ++s) h->step_off[s + 1] += h->step_off[s];
+    std::vector<int64_t> cur(h->step_off.begin(), h->step_off.end() - 1);
+    std::vector<int32_t> su((size_t)N), si((size_t)N);
+    std::vector<uint32_t> sp((size_t)N), sl((size_t)N);
+    for (int64_t q = 0; q < N; ++q) {   // stable: item order inside each step
+        const uint32_t l = by_item[q];
+        const int64_t p = cur[step_of(l)]++;
+        su[p] = h->h_users[l]; si[p] = h->h_pos_items[l]; sp[p] = h->h_gpos[l]; sl[p] = l;
+    }
+    CYMF_TRY(h->d_slot_user.upload(su.data(), su.size(), h->stream));
+    CYMF_TRY(h->d_slot_item.upload(si.data(), si.size(), h->stream));
+    CYMF_TRY(h->d_slot_pos.upload(sp.data(), sp.size(), h->stream));
+    CYMF_TRY(h->d_slot_local.upload(sl.data(), sl.size(), h->stream));
+    CYMF_TRY(h->d_slot_neg.alloc((size_t)N));
+    CYMF_TRY(h->d_skipped.alloc(1));
+    CYMF_TRY(h->d_skipped.zero(h->stream));
+    CYMF_TRY(h->d_performed.alloc(1));
+    CYMF_TRY(h->d_performed.zero(h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int drain_profile(cymf_bpr *h) {
+    for (auto &pe : h->prof_events) {
+        float ms = 0;
+        CYMF_HIP(hipEventSynchronize(pe.second));
+        CYMF_HIP(hipEventElapsedTime(&ms, pe.first, pe.second));
+        h->prof_ms += ms;
+        h->prof_pool.push_back(pe.first);
+        h->prof_pool.push_back(pe.second);
+    }
+    h->prof_events.clear();
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================
+//                                        C ABI
+// =====================================================================================
+extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, int optimizer, double learning_rate,
+                               double weight_decay, uint32_t neg_seed, int dtype, int mode, int device) {
+    if (!out) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: out is NULL");
+    *out = nullptr;
+    if (U <= 0 || I <= 0 || K <= 0) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: U, I, K must be positive");
+    if (K > 256) return fail(CYMF_ERR_UNSUPPORTED, "cymf_bpr_create: K=%d > 256 (4 factors per lane) is not built", K);
+    if (optimizer < 0 || optimizer > 2) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: optimizer id %d", optimizer);
+    if (dtype != CYMF_F32 && dtype != CYMF_F64) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: dtype %d", dtype);
+    if (mode != CYMF_MODE_EXACT && mode != CYMF_MODE_THROUGHPUT) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: mode %d", mode);
+    if (mode == CYMF_MODE_THROUGHPUT && dtype != CYMF_F32)
+        return fail(CYMF_ERR_UNSUPPORTED, "throughput mode computes in f32 only (f64 is the exact-order parity path)");
+    CYMF_TRY(use_device(device));
+    cymf_bpr *h = new cymf_bpr();
+    h->U = U; h->I = I; h->K = K; h->opt = optimizer; h->lr = learning_rate; h->wd = weight_decay;
+    h->seed = neg_seed; h->dtype = dtype; h->mode = mode; h->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->rng_stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        e = hipEventCreateWithFlags(&h->ev_gen[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
+    int rc = h->d_loss.alloc(1);
+    if (rc) { delete h; return rc; }
+    if (mode == CYMF_MODE_THROUGHPUT) {
+        // HOGWILD updates rows from all 8 XCDs inside one kernel, and the per-XCD L2s are not coherent
+        // with each other: with cacheable memory each XCD trains a private copy of a row and the last
+        // write-back wins (measured: learning stalls).  Uncached device memory keeps every access at the
+        // memory side (Infinity Cache / HBM), which is where these random row gathers are served anyway.
+        const int f = getenv("CYMF_BPR_MEMTYPE") ? atoi(getenv("CYMF_BPR_MEMTYPE")) : 2;
+        h->f32.W.fine = h->f32.H.fine = h->f32.W0.fine = h->f32.W1.fine = h->f32.H0.fine = h->f32.H1.fine = f;
+    }
+    if (const char *e3 = getenv("CYMF_BPR_XCD_STRIDE")) h->xcd_stride = std::max(1, atoi(e3));
+    if (const char *e1 = getenv("CYMF_BPR_MAX_WAVES")) h->max_waves = std::max(1, atoi(e1));
+    if (const char *e2 = getenv("CYMF_BPR_ROWS_PER_INFLIGHT")) h->rows_per_inflight = std::max(1, atoi(e2));
+    *out = h;
+    return 0;
+}
+
+extern "C" int cymf_bpr_set_steps_per_epoch(cymf_bpr *h, int32_t steps) {
+    if (!h || steps < 1) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_steps_per_epoch: bad arguments");
+    if (h->have_data) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_steps_per_epoch must precede cymf_bpr_set_data");
+    h->steps_per_epoch = steps;
+    return 0;
+}
+
+extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_t *positives, int64_t N,
+                                 const int32_t *indptr, const int32_t *indices, const int64_t *global_pos,
+                                 int64_t N_global) {
+    if (!h || N < 0 || (N > 0 && (!users || !positives)) || !indptr)
+        return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: bad arguments");
+    CYMF_TRY(use_device(h->device));
+    if (!global_pos) N_global = N;
+    if (N_global < N || N_global >= (int64_t)0xffffffffll)
+        return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: N_global=%lld must be in [N, 2^32-1)", (long long)N_global);
+    const int64_t nnz = indptr[h->U];
+    if (nnz < 0 || (nnz > 0 && !indices)) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: bad CSR");
+    // host-side validation: a bad index would fault the kernels
+    for (int32_t u = 0; u < h->U; ++u) {
+        if (indptr[u] > indptr[u + 1]) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: indptr not monotone at %d", u);
+        for (int32_t p = indptr[u]; p < indptr[u + 1]; ++p) {
+            if (indices[p] < 0 || indices[p] >= h->I) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: item index out of range");
+            if (p > indptr[u] && indices[p - 1] > indices[p])
+                return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: CSR indices of user %d are not sorted", u);
+        }
+    }
+    for (int64_t l = 0; l < N; ++l) {
+        if (users[l] < 0 || users[l] >= h->U || positives[l] < 0 || positives[l] >= h->I)
+            return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: triplet %lld out of range", (long long)l);
+        if (global_pos && (global_pos[l] < 0 || global_pos[l] >= N_global))
+            return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: global_pos[%lld] out of range", (long long)l);
+    }
+    h->N = N; h->N_global = N_global;
+    h->h_users.assign(users, users + N);
+    h->h_pos_items.assign(positives, positives + N);
+    h->h_gpos.resize((size_t)N);
+    for (int64_t l = 0; l < N; ++l) h->h_gpos[l] = (uint32_t)(global_pos ? global_pos[l] : l);
+    h->h_indptr.assign(indptr, indptr + h->U + 1);
+    h->h_indices.assign(indices, indices + nnz);
+    CYMF_TRY(h->d_indptr.upload(h->h_indptr.data(), h->h_indptr.size(), h->stream));
+    CYMF_TRY(h->d_indices.upload(h->h_indices.data(), h->h_indices.size(), h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    if (!h->rng_ready) {   // ONE generator for the whole fit (bpr.pyx:141)
+        CYMF_TRY(h->rng.init(h->seed, (uint64_t)h->I, h->rng_stream));
+        h->rng_ready = true;
+    }
+    if (h->mode == CYMF_MODE_THROUGHPUT) CYMF_TRY(build_throughput_layout(h));
+    h->have_data = true;
+    return 0;
+}
+
+template <typename T>
+static int upload_store(cymf_bpr *h, BprStore<T> &st, const double *W, const double *H) {
+    const size_t nW = (size_t)h->U * h->K, nH = (size_t)h->I * h->K;
+    CYMF_TRY(upload_f64(st.W, W, nW, h->stream));
+    CYMF_TRY(upload_f64(st.H, H, nH, h->stream));
+    if (h->opt == CYMF_OPT_ADAGRAD) {          // accumulators start at ONE (optimizer.pyx:69-70)
+        CYMF_TRY(fill_dev<T>(st.W0, nW, (T)1, h->stream));
+        CYMF_TRY(fill_dev<T>(st.H0, nH, (T)1, h->stream));
+    } else if (h->opt == CYMF_OPT_ADAM) {      // zeros (optimizer.pyx:143-146)
+        CYMF_TRY(fill_dev<T>(st.W0, nW, (T)0, h->stream));
+        CYMF_TRY(fill_dev<T>(st.W1, nW, (T)0, h->stream));
+        CYMF_TRY(fill_dev<T>(st.H0, nH, (T)0, h->stream));
+        CYMF_TRY(fill_dev<T>(st.H1, nH, (T)0, h->stream));
+    }
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int cymf_bpr_upload(cymf_bpr *h, const double *W, const double *H) {
+    if (!h || !W || !H) return fail(CYMF_ERR_INVALID, "cymf_bpr_upload: bad arguments");
+    CYMF_TRY(use_device(h->device));
+    if (h->dtype == CYMF_F32) CYMF_TRY(upload_store(h, h->f32, W, H));
+    else CYMF_TRY(upload_store(h, h->f64, W, H));
+    if (h->comm) {
+        const size_t n = (size_t)h->I * h->K;
+        CYMF_TRY(h->d_snap.alloc(n));
+        CYMF_TRY(h->d_delta.alloc(n));
+        CYMF_HIP(hipMemcpyAsync(h->d_snap.p, h->f32.H.p, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+    }
+    h->have_params = true;
+    return 0;
+}
+
+extern "C" int cymf_bpr_download(cymf_bpr *h, double *W, double *H) {
+    if (!h || !W || !H) return fail(CYMF_ERR_INVALID, "cymf_bpr_download: bad arguments");
+    if (!h->have_params) return fail(CYMF_ERR_INVALID, "cymf_bpr_download before cymf_bpr_upload");
+    CYMF_TRY(use_device(h->device));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    const size_t nW = (size_t)h->U * h->K, nH = (size_t)h->I * h->K;
+    if (h->dtype == CYMF_F32) { CYMF_TRY(download_f64(h->f32.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f32.H, H, nH, h->stream)); }
+    else { CYMF_TRY(download_f64(h->f64.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f64.H, H, nH, h->stream)); }
+    return 0;
+}
+
+extern "C" int cymf_bpr_steps(cymf_bpr *h, int32_t n_steps, double *loss_sum_out) {
+    if (!h || n_steps < 0) return fail(CYMF_ERR_INVALID, "cymf_bpr_steps: bad arguments");
+    if (!h->have_params || !h->have_data) return fail(CYMF_ERR_INVALID, "cymf_bpr_steps before upload/set_data");
+    if (h->mode != CYMF_MODE_THROUGHPUT) return fail(CYMF_ERR_INVALID, "cymf_bpr_steps needs CYMF_MODE_THROUGHPUT");
+    CYMF_TRY(use_device(h->device));
+    if (loss_sum_out) CYMF_TRY(h->d_loss.zero(h->stream));
+    for (int32_t s = 0; s < n_steps; ++s) CYMF_TRY(run_one_step(h));
+    if (loss_sum_out) CYMF_TRY(fetch_loss(h, loss_sum_out));
+    return 0;
+}
+
+extern "C" int cymf_bpr_epochs(cymf_bpr *h, int32_t n_epochs, double *loss_out) {
+    if (!h || n_epochs < 0) return fail(CYMF_ERR_INVALID, "cymf_bpr_epochs: bad arguments");
+    if (!h->have_params || !h->have_data) return fail(CYMF_ERR_INVALID, "cymf_bpr_epochs before upload/set_data");
+    CYMF_TRY(use_device(h->device));
+    if (h->mode == CYMF_MODE_EXACT) {
+        if (h->comm) return fail(CYMF_ERR_UNSUPPORTED, "exact (sequential-order) mode is single-GPU by definition");
+        for (int32_t e = 0; e < n_epochs; ++e) {
+            double *lo = loss_out ? loss_out + e : nullptr;
+            if (h->dtype == CYMF_F32) CYMF_TRY(epoch_exact<float>(h, h->f32, lo));
+            else CYMF_TRY(epoch_exact<double>(h, h->f64, lo));
+        }
+        return 0;
+    }
+    if (h->step_cursor != 0) return fail(CYMF_ERR_INVALID, "cymf_bpr_epochs called in the middle of an epoch");
+    for (int32_t e = 0; e < n_epochs; ++e) {
+        double loss = 0;
+        CYMF_TRY(cymf_bpr_steps(h, h->steps_per_epoch, loss_out ? &loss : nullptr));
+        if (loss_out) loss_out[e] = h->N ? loss / (double)h->N : 0.0;
+    }
+    return 0;
+}
+
+extern "C" int cymf_bpr_sync(cymf_bpr *h) {
+    if (!h) return fail(CYMF_ERR_INVALID, "cymf_bpr_sync: NULL handle");
+    CYMF_TRY(use_device(h->device));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int cymf_bpr_stats(cymf_bpr *h, int64_t *performed, int64_t *skipped) {
+    if (!h) return fail(CYMF_ERR_INVALID, "cymf_bpr_stats: NULL handle");
+    CYMF_TRY(use_device(h->device));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    if (h->mode == CYMF_MODE_THROUGHPUT && h->have_data) CYMF_TRY(collect_skips(h));
+    if (performed) *performed = h->performed;
+    if (skipped) *skipped = h->skipped;
+    return 0;
+}
+
+extern "C" int cymf_bpr_set_profiling(cymf_bpr *h, int on) {
+    if (!h) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_profiling: NULL handle");
+    h->profiling = on != 0;
+    return 0;
+}
+
+extern "C" int cymf_bpr_kernel_time(cymf_bpr *h, double *ms_total, int64_t *launches, int64_t *units) {
+    if (!h) return fail(CYMF_ERR_INVALID, "cymf_bpr_kernel_time: NULL handle");
+    CYMF_TRY(use_device(h->device));
+    CYMF_TRY(drain_profile(h));
+    if (ms_total) *ms_total = h->prof_ms;
+    if (launches) *launches = h->prof_launches;
+    if (units) *units = h->prof_units;
+    h->prof_ms = 0; h->prof_launches = 0; h->prof_units = 0;
+    return 0;
+}
+
+extern "C" int cymf_bpr_last_negatives(cymf_bpr *h, int32_t *out, int64_t n) {
+    if (!h || !out || n != h->N) return fail(CYMF_ERR_INVALID, "cymf_bpr_last_negatives: n must equal N");
+    CYMF_TRY(use_device(h->device));
+    if (h->mode == CYMF_MODE_EXACT) {
+        if ((int64_t)h->h_last_neg.size() != n) return fail(CYMF_ERR_INVALID, "no epoch has run yet");
+        memcpy(out, h->h_last_neg.data(), (size_t)n * sizeof(int32_t));
+        return 0;
+    }
+    if (n == 0) return 0;
+    CYMF_TRY(h->d_unsorted_neg.alloc((size_t)n));
+    hipLaunchKernelGGL(bpr_unsort_neg_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->d_slot_neg.p, h->d_slot_local.p,
+                       h->d_unsorted_neg.p, n);
+    CYMF_HIP(hipGetLastError());
+    CYMF_HIP(hipMemcpyAsync(out, h->d_unsorted_neg.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int cymf_bpr_attach_comm(cymf_bpr *h, cymf_comm *c) {
+    if (!h || !c) return fail(CYMF_ERR_INVALID, "cymf_bpr_attach_comm: bad arguments");
+    if (h->mode != CYMF_MODE_THROUGHPUT) return fail(CYMF_ERR_UNSUPPORTED, "a communicator needs throughput mode");
+    if (h->opt != CYMF_OPT_SGD) return fail(CYMF_ERR_UNSUPPORTED, "multi-GPU item-delta exchange is built for sgd only");
+    if (h->have_params) return fail(CYMF_ERR_INVALID, "cymf_bpr_attach_comm must precede cymf_bpr_upload");
+    h->comm = c;
+    return 0;
+}
+
+extern "C" int cymf_bpr_destroy(cymf_bpr *h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->rng_stream) (void)hipStreamSynchronize(h->rng_stream);
+    for (auto &pe : h->prof_events) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
+    for (auto &e : h->prof_pool) (void)hipEventDestroy(e);
+    for (int b = 0; b < 2; ++b) {
+        if (h->ev_gen[b]) (void)hipEventDestroy(h->ev_gen[b]);
+        if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
+    }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->rng_stream) (void)hipStreamDestroy(h->rng_stream);
+    delete h;
+    return 0;
+}

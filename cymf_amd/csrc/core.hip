@@ -1,0 +1,74 @@
+// core.hip -- error state, device selection, library info.
+#include "common.h"
+
+namespace cymf {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+static int device_count_quiet() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int use_device(int device) {
+    int n = device_count_quiet();
+    if (n <= 0)
+        return fail(CYMF_ERR_NO_DEVICE, "no HIP device visible: libcymf_hip has no CPU fallback (gfx950 required)");
+    if (device < 0 || device >= n) return fail(CYMF_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    CYMF_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CYMF_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    CYMF_HIP(hipSetDevice(device));
+    return 0;
+}
+
+}  // namespace cymf
+
+using namespace cymf;
+
+extern "C" const char *cymf_last_error(void) { return g_err.c_str(); }
+extern "C" int cymf_version(void) { return 100; }
+extern "C" int cymf_device_count(void) { return device_count_quiet(); }
+
+extern "C" int cymf_device_name(int device, char *buf, int buflen) {
+    if (!buf || buflen <= 0) return fail(CYMF_ERR_INVALID, "cymf_device_name: bad buffer");
+    int n = device_count_quiet();
+    if (n <= 0) return fail(CYMF_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(CYMF_ERR_INVALID, "device %d out of range", device);
+    hipDeviceProp_t prop;
+    CYMF_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+extern "C" int cymf_device_sync(int device) {
+    CYMF_TRY(use_device(device));
+    CYMF_HIP(hipDeviceSynchronize());
+    return 0;
+}

@@ -1,0 +1,99 @@
+// rows.h -- one embedding row spread over the 64 lanes of a wavefront, and the fused
+// optimizer update rules (cymf/optimizer.pyx:40-160).  Shared by the BPR / RelMF / GloVe kernels.
+#pragma once
+#include "common.h"
+
+namespace cymf {
+
+#if defined(__HIPCC__)
+
+// A row of K factors held by one wavefront.
+//   PACKED  (K == 64*R): lane l owns k = l*R .. l*R+R-1  -> ONE dwordx{R} access per lane,
+//                        64*R*sizeof(T) contiguous bytes per wave instruction.
+//   STRIDED (any K <= 64*R): lane l owns k = l, l+64, ... -> R dword accesses, each a
+//                        contiguous 64*sizeof(T)-byte segment; lanes past K are masked and hold 0.
+template <typename T, int R, bool PACKED>
+struct Row {
+    T v[R];
+
+    struct alignas(sizeof(T) * R) Vec { T x[R]; };
+
+    __device__ __forceinline__ void load(const T *__restrict__ base, int K, int lane) {
+        if constexpr (PACKED) {
+            Vec t = *reinterpret_cast<const Vec *>(base + lane * R);
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = t.x[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int k = lane + 64 * r;
+                v[r] = k < K ? base[k] : T(0);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(T *__restrict__ base, int K, int lane) const {
+        if constexpr (PACKED) {
+            Vec t;
+#pragma unroll
+            for (int r = 0; r < R; ++r) t.x[r] = v[r];
+            *reinterpret_cast<Vec *>(base + lane * R) = t;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int k = lane + 64 * r;
+                if (k < K) base[k] = v[r];
+            }
+        }
+    }
+    // element index of slot r (for atomics on single elements)
+    __device__ __forceinline__ static int kof(int lane, int r) { return PACKED ? lane * R + r : lane + 64 * r; }
+    __device__ __forceinline__ void fill(T x) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = x;
+    }
+};
+
+// Update rules.  s0/s1 are the per-element optimizer state (unused ones are ignored):
+//   SGD      cymf/optimizer.pyx:52-58    p -= lr*g
+//   AdaGrad  cymf/optimizer.pyx:74-82    acc += g^2 (acc starts at 1, :69-70); p -= lr*g/sqrt(acc)
+//   Adam     cymf/optimizer.pyx:150-160  constant "bias correction" 1/(1-beta), no step counter
+template <typename T>
+struct OptParams {
+    T lr;
+    T b1, b2, omb1, omb2, eps;   // Adam: beta1, beta2, (1-beta1), (1-beta2), epsilon
+};
+
+template <typename T>
+inline OptParams<T> make_opt_params(double lr) {
+    OptParams<T> p;
+    p.lr = (T)lr;
+    p.b1 = (T)0.9;
+    p.b2 = (T)0.999;
+    p.omb1 = (T)(1 - 0.9);
+    p.omb2 = (T)(1 - 0.999);
+    p.eps = (T)1e-8;
+    return p;
+}
+
+__device__ __forceinline__ float fsqrt(float x) { return __fsqrt_rn(x); }
+__device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
+
+template <typename T, int OPT>
+__device__ __forceinline__ void opt_update(const OptParams<T> &o, T &p, T &s0, T &s1, T g) {
+    if constexpr (OPT == CYMF_OPT_SGD) {
+        p -= o.lr * g;
+    } else if constexpr (OPT == CYMF_OPT_ADAGRAD) {
+        s0 += g * g;
+        p -= o.lr * g / fsqrt(s0);
+    } else {
+        s0 = o.b1 * s0 + o.omb1 * g;
+        s1 = o.b2 * s1 + o.omb2 * (g * g);
+        p -= o.lr * (s0 / o.omb1) / (fsqrt(s1 / o.omb2) + o.eps);
+    }
+}
+
+constexpr int opt_num_states(int opt) { return opt == CYMF_OPT_SGD ? 0 : (opt == CYMF_OPT_ADAGRAD ? 1 : 2); }
+
+#endif  // __HIPCC__
+
+}  // namespace cymf

@@ -1,0 +1,545 @@
+// sgd_models.hip -- the two other per-sample SGD loops of the reference on the BPR skeleton
+// (one wavefront per sample, K across lanes, DPP reduction, fused optimizer):
+//   RelMF : RelMF._fit_relmf  cymf/relmf.pyx:106-171 (loop :142-148),
+//           RelMfModel.forward/backward cymf/model.pyx:99-142
+//   GloVe : GloVe._fit_glove  cymf/glove.pyx:117-162 (loop :149-156),
+//           GloVeModel.forward/backward cymf/model.pyx:166-204, GloVeAdaGrad cymf/optimizer.pyx:85-123
+// EXACT mode = the reference's sequential order by level scheduling over the two rows a sample
+// touches; THROUGHPUT mode = HOGWILD over the same samples, one launch per epoch.
+#include <algorithm>
+#include <cmath>
+
+#include "store.h"
+
+namespace cymf {
+namespace {
+
+// ------------------------------------------------------------------ level scheduling (host)
+// Samples s = 0..n-1 touch row a[s] of table A and row b[s] of table B.  Returns the samples
+// ordered by level (stable) and the level offsets; two samples of one level share no row.
+void level_schedule(int64_t n, const int32_t *a, const int32_t *b, int32_t nA, int32_t nB,
+                    std::vector<int64_t> &order, std::vector<int64_t> &off) {
+    std::vector<int32_t> lastA((size_t)nA, 0), lastB((size_t)nB, 0), level((size_t)n);
+    int32_t nl = 0;
+    for (int64_t s = 0; s < n; ++s) {
+        int32_t lv = std::max(lastA[a[s]], lastB[b[s]]) + 1;
+        lastA[a[s]] = lastB[b[s]] = lv;
+        level[s] = lv;
+        nl = std::max(nl, lv);
+    }
+    off.assign((size_t)nl + 2, 0);
+    for (int64_t s = 0; s < n; ++s) off[level[s] + 1]++;
+    for (int32_t v = 1; v <= nl + 1; ++v) off[v] += off[v - 1];
+    std::vector<int64_t> cur(off.begin(), off.end());
+    order.resize((size_t)n);
+    for (int64_t s = 0; s < n; ++s) order[(size_t)cur[level[s]]++] = s;
+    // off[lv] .. off[lv+1] is level lv (1-based); off[0] == off[1] == 0
+}
+
+inline int ew_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// ================================================================== RelMF
+template <typename T>
+struct RelDev {
+    T *W, *H, *W0, *W1, *H0, *H1;
+    const T *X;       // dense (U,I)
+    const T *prop;    // (I)
+    int K;
+    int64_t I;
+    T wd, clip;
+    OptParams<T> opt;
+};
+
+// One draw: cell index -> (u, i) = (cell / I, cell % I)  (relmf.pyx:144-146)
+template <typename T, int R, bool PACKED, int OPT>
+__global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const uint32_t *__restrict__ cells, int64_t n,
+                                                   double *__restrict__ loss_acc) {
+    const int lane = lane_id();
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int NS = opt_num_states(OPT);
+    const int K = d.K;
+    double loss_sum = 0.0;
+    for (int64_t s = wave0; s < n; s += n_waves) {
+        const uint32_t cell = cells[s];
+        const int64_t u = cell / (uint32_t)d.I, i = cell % (uint32_t)d.I;
+        const T r = d.X[u * d.I + i], p = d.prop[i];
+        const int64_t ou = u * K, oi = i * K;
+        Row<T, R, PACKED> w, h, sw[NS ? NS : 1], sh[NS ? NS : 1];
+        w.load(d.W + ou, K, lane);
+        h.load(d.H + oi, K, lane);
+        if constexpr (NS >= 1) { sw[0].load(d.W0 + ou, K, lane); sh[0].load(d.H0 + oi, K, lane); }
+        if constexpr (NS >= 2) { sw[1].load(d.W1 + ou, K, lane); sh[1].load(d.H1 + oi, K, lane); }
+        T py = 0, pl = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            py += w.v[q] * h.v[q];
+            pl += w.v[q] * w.v[q] + h.v[q] * h.v[q];
+        }
+        const T y = wave_sum(py), l2 = wave_sum(pl);
+        const T qq = r / (p >= d.clip ? p : d.clip);                                  // r / dmax(p, M)
+        loss_sum += (double)(qq * (1 - y) * (1 - y) + (1 - qq) * y * y + d.wd * l2);  // model.pyx:117
+        const T c = qq * (1 - y) + (1 - qq) * (0 - y);                                // model.pyx:131-139 (no factor 2)
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const T wv = w.v[q], hv = h.v[q];
+            const T gw = -(c * hv) + d.wd * wv;
+            const T gh = -(c * wv) + d.wd * hv;
+            T dummy = 0;
+            opt_update<T, OPT>(d.opt, w.v[q], OPT >= 1 ? sw[0].v[q] : dummy, OPT == 2 ? sw[1].v[q] : dummy, gw);
+            opt_update<T, OPT>(d.opt, h.v[q], OPT >= 1 ? sh[0].v[q] : dummy, OPT == 2 ? sh[1].v[q] : dummy, gh);
+        }
+        w.store(d.W + ou, K, lane);
+        h.store(d.H + oi, K, lane);
+        if constexpr (NS >= 1) { sw[0].store(d.W0 + ou, K, lane); sh[0].store(d.H0 + oi, K, lane); }
+        if constexpr (NS >= 2) { sw[1].store(d.W1 + ou, K, lane); sh[1].store(d.H1 + oi, K, lane); }
+    }
+    if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
+}
+
+// ================================================================== GloVe
+template <typename T>
+struct GloveDev {
+    T *W, *H, *bW, *bH;       // central / context factors and biases
+    T *aW, *aH, *abW, *abH;   // AdaGrad accumulators (init ones, optimizer.pyx:96-99)
+    int K;
+    T lr, x_max, alpha;
+};
+
+__device__ __forceinline__ float fpow(float a, float b) { return powf(a, b); }
+__device__ __forceinline__ double fpow(double a, double b) { return pow(a, b); }
+__device__ __forceinline__ float flog(float a) { return logf(a); }
+__device__ __forceinline__ double flog(double a) { return log(a); }
+
+template <typename T, int R, bool PACKED>
+__global__ __launch_bounds__(256) void glove_kernel(GloveDev<T> d, const int32_t *__restrict__ central,
+                                                   const int32_t *__restrict__ context,
+                                                   const T *__restrict__ counts, int64_t n,
+                                                   double *__restrict__ loss_acc) {
+    const int lane = lane_id();
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int K = d.K;
+    double loss_sum = 0.0;
+    for (int64_t s = wave0; s < n; s += n_waves) {
+        const int64_t c = central[s], x = context[s];
+        const T cnt = counts[s];
+        const int64_t oc = c * K, ox = x * K;
+        Row<T, R, PACKED> w, h, aw, ah;
+        w.load(d.W + oc, K, lane);
+        h.load(d.H + ox, K, lane);
+        aw.load(d.aW + oc, K, lane);
+        ah.load(d.aH + ox, K, lane);
+        T bw = d.bW[c], bh = d.bH[x], abw = d.abW[c], abh = d.abH[x];
+        T pd = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) pd += w.v[q] * h.v[q];
+        T diff = wave_sum(pd);                                      // model.pyx:174-175
+        diff += bw + bh;                                            // :176
+        diff -= flog(cnt);                                          // :177
+        const T tmp = diff;
+        const T f = fpow(cnt / d.x_max, d.alpha);
+        diff *= f < (T)1 ? f : (T)1;                                // :179, weight_func :34-35
+        loss_sum += (double)((T)0.5 * diff * tmp);                  // :180
+        const T g2 = diff * diff;
+        // biases: AdaGrad-updated K times per sample (model.pyx:195-204):
+        //   acc_k = acc_0 + k g^2,  b_K = b_0 - lr g sum_{k=1..K} 1/sqrt(acc_k); lanes share the k's
+        T pbw = 0, pbh = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int k = Row<T, R, PACKED>::kof(lane, q);
+            if (k < K) {
+                pbw += (T)1 / fsqrt(abw + (T)(k + 1) * g2);
+                pbh += (T)1 / fsqrt(abh + (T)(k + 1) * g2);
+            }
+            const T wv = w.v[q], hv = h.v[q];
+            const T gw = diff * hv, gh = diff * wv;
+            aw.v[q] += gw * gw;
+            w.v[q] -= d.lr * gw / fsqrt(aw.v[q]);
+            ah.v[q] += gh * gh;
+            h.v[q] -= d.lr * gh / fsqrt(ah.v[q]);
+        }
+        const T sbw = wave_sum(pbw), sbh = wave_sum(pbh);
+        w.store(d.W + oc, K, lane);
+        h.store(d.H + ox, K, lane);
+        aw.store(d.aW + oc, K, lane);
+        ah.store(d.aH + ox, K, lane);
+        if (lane == 0) {
+            d.bW[c] = bw - d.lr * diff * sbw;
+            d.bH[x] = bh - d.lr * diff * sbh;
+            d.abW[c] = abw + (T)K * g2;
+            d.abH[x] = abh + (T)K * g2;
+        }
+    }
+    if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
+}
+
+#define CYMF_DISPATCH_LAYOUT(K, CALL)                                                          \
+    do {                                                                                       \
+        const int R__ = ((K) + 63) / 64;                                                       \
+        const bool P__ = (K) == 128 || (K) == 256;                                             \
+        if (R__ == 1) { CALL(1, false); }                                                      \
+        else if (R__ == 2) { if (P__) { CALL(2, true); } else { CALL(2, false); } }            \
+        else if (R__ == 3) { CALL(3, false); }                                                 \
+        else { if (P__) { CALL(4, true); } else { CALL(4, false); } }                          \
+    } while (0)
+
+template <typename T, int R, bool PACKED>
+void launch_relmf_opt(int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, double *loss, int grid,
+                      hipStream_t s) {
+    switch (opt) {
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_SGD>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAGRAD>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    default: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAM>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    }
+}
+
+template <typename T>
+void launch_relmf(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, double *loss, int grid,
+                  hipStream_t s) {
+#define CALL_(R_, P_) launch_relmf_opt<T, R_, P_>(opt, d, cells, n, loss, grid, s)
+    CYMF_DISPATCH_LAYOUT(K, CALL_);
+#undef CALL_
+}
+
+template <typename T>
+void launch_glove(int K, const GloveDev<T> &d, const int32_t *c, const int32_t *x, const T *cnt, int64_t n,
+                  double *loss, int grid, hipStream_t s) {
+#define CALL_(R_, P_) hipLaunchKernelGGL((glove_kernel<T, R_, P_>), dim3(grid), dim3(256), 0, s, d, c, x, cnt, n, loss)
+    CYMF_DISPATCH_LAYOUT(K, CALL_);
+#undef CALL_
+}
+
+// HOGWILD launches: the number of wavefronts bounds the staleness.  With waves striding over the
+// samples, about waves * f_max of them hold the hottest row at once (f_max = its share of the
+// samples), so waves <= hot_budget / f_max keeps that number at hot_budget; 8 waves per CU at most.
+inline int hogwild_grid(int64_t n, double f_max) {
+    const double hot_budget = 2.0;
+    int64_t waves = f_max > 0 ? (int64_t)(hot_budget / f_max) : n;
+    waves = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(waves, n), 256 * 8));
+    return (int)((waves + 3) / 4);
+}
+
+}  // namespace
+}  // namespace cymf
+
+using namespace cymf;
+
+// =====================================================================================
+//                                        RelMF
+// =====================================================================================
+template <typename T>
+struct RelStore {
+    DevBuf<T> W, H, W0, W1, H0, H1, X, prop;
+};
+
+struct cymf_relmf {
+    int32_t U = 0, I = 0, K = 0;
+    int opt = 0, dtype = 0, mode = 0, device = 0;
+    double lr = 0, wd = 0, clip = 0;
+    uint32_t seed = 1234;
+    hipStream_t stream = nullptr;
+    RelStore<float> f32;
+    RelStore<double> f64;
+    DeviceRng rng;
+    DevBuf<uint32_t> d_cells, d_sorted;
+    DevBuf<double> d_loss;
+    std::vector<uint32_t> h_cells;
+    bool have_data = false, have_params = false;
+};
+
+template <typename T>
+static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
+    const int64_t N = (int64_t)h->U * h->I;   // relmf.pyx:120: one epoch = U*I draws with replacement
+    CYMF_TRY(h->d_cells.alloc((size_t)N));
+    CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, h->stream));
+    RelDev<T> d;
+    d.W = st.W.p; d.H = st.H.p; d.W0 = st.W0.p; d.W1 = st.W1.p; d.H0 = st.H0.p; d.H1 = st.H1.p;
+    d.X = st.X.p; d.prop = st.prop.p; d.K = h->K; d.I = h->I; d.wd = (T)h->wd; d.clip = (T)h->clip;
+    d.opt = make_opt_params<T>(h->lr);
+    CYMF_TRY(h->d_loss.zero(h->stream));
+    if (h->mode == CYMF_MODE_THROUGHPUT) {
+        launch_relmf<T>(h->K, h->opt, d, h->d_cells.p, N, h->d_loss.p, hogwild_grid(N, 1.0 / std::min(h->U, h->I)), h->stream);
+        CYMF_HIP(hipGetLastError());
+    } else {
+        h->h_cells.resize((size_t)N);
+        CYMF_HIP(hipMemcpyAsync(h->h_cells.data(), h->d_cells.p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+        std::vector<int32_t> su((size_t)N), si((size_t)N);
+        for (int64_t s = 0; s < N; ++s) {
+            su[s] = (int32_t)(h->h_cells[s] / (uint32_t)h->I);
+            si[s] = (int32_t)(h->h_cells[s] % (uint32_t)h->I);
+        }
+        std::vector<int64_t> order, off;
+        level_schedule(N, su.data(), si.data(), h->U, h->I, order, off);
+        std::vector<uint32_t> sorted((size_t)N);
+        for (int64_t p = 0; p < N; ++p) sorted[p] = h->h_cells[(size_t)order[p]];
+        CYMF_TRY(h->d_sorted.upload(sorted.data(), sorted.size(), h->stream));
+        for (size_t lv = 1; lv + 1 < off.size(); ++lv) {
+            const int64_t b = off[lv], n = off[lv + 1] - off[lv];
+            if (n > 0) launch_relmf<T>(h->K, h->opt, d, h->d_sorted.p + b, n, h->d_loss.p, (int)((n + 3) / 4), h->stream);
+        }
+        CYMF_HIP(hipGetLastError());
+    }
+    double loss = 0;
+    CYMF_HIP(hipMemcpyAsync(&loss, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    if (loss_out) *loss_out = loss;
+    return 0;
+}
+
+extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t K, int optimizer,
+                                 double learning_rate, double weight_decay, double clip_value, uint32_t seed,
+                                 int dtype, int mode, int device) {
+    if (!out) return fail(CYMF_ERR_INVALID, "cymf_relmf_create: out is NULL");
+    *out = nullptr;
+    if (U <= 0 || I <= 0 || K <= 0) return fail(CYMF_ERR_INVALID, "cymf_relmf_create: U, I, K must be positive");
+    if (K > 256) return fail(CYMF_ERR_UNSUPPORTED, "cymf_relmf_create: K=%d > 256 is not built", K);
+    if (optimizer < 0 || optimizer > 2 || (dtype != CYMF_F32 && dtype != CYMF_F64) ||
+        (mode != CYMF_MODE_EXACT && mode != CYMF_MODE_THROUGHPUT))
+        return fail(CYMF_ERR_INVALID, "cymf_relmf_create: bad optimizer/dtype/mode");
+    CYMF_TRY(use_device(device));
+    cymf_relmf *h = new cymf_relmf();
+    h->U = U; h->I = I; h->K = K; h->opt = optimizer; h->lr = learning_rate; h->wd = weight_decay;
+    h->clip = clip_value; h->seed = seed; h->dtype = dtype; h->mode = mode; h->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    if (mode == CYMF_MODE_THROUGHPUT) {   // rows are updated from all XCDs inside one kernel: see bpr.hip
+        for (DevBuf<float> *b : {&h->f32.W, &h->f32.H, &h->f32.W0, &h->f32.W1, &h->f32.H0, &h->f32.H1}) b->fine = 2;
+        for (DevBuf<double> *b : {&h->f64.W, &h->f64.H, &h->f64.W0, &h->f64.W1, &h->f64.H0, &h->f64.H1}) b->fine = 2;
+    }
+    int rc = h->d_loss.alloc(1);
+    if (!rc) rc = h->rng.init(seed, (uint64_t)U * (uint64_t)I, h->stream);   // relmf.pyx:128
+    if (rc) { (void)hipStreamDestroy(h->stream); delete h; return rc; }
+    *out = h;
+    return 0;
+}
+
+extern "C" int cymf_relmf_set_data(cymf_relmf *h, const double *X, const double *propensities) {
+    if (!h || !X || !propensities) return fail(CYMF_ERR_INVALID, "cymf_relmf_set_data: bad arguments");
+    CYMF_TRY(use_device(h->device));
+    const size_t n = (size_t)h->U * h->I;
+    if (h->dtype == CYMF_F32) { CYMF_TRY(upload_f64(h->f32.X, X, n, h->stream)); CYMF_TRY(upload_f64(h->f32.prop, propensities, (size_t)h->I, h->stream)); }
+    else { CYMF_TRY(upload_f64(h->f64.X, X, n, h->stream)); CYMF_TRY(upload_f64(h->f64.prop, propensities, (size_t)h->I, h->stream)); }
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    h->have_data = true;
+    return 0;
+}
+
+template <typename T>
+static int relmf_upload(cymf_relmf *h, RelStore<T> &st, const double *W, const double *H) {
+    const size_t nW = (size_t)h->U * h->K, nH = (size_t)h->I * h->K;
+    CYMF_TRY(upload_f64(st.W, W, nW, h->stream));
+    CYMF_TRY(upload_f64(st.H, H, nH, h->stream));
+    if (h->opt == CYMF_OPT_ADAGRAD) {
+        CYMF_TRY(fill_dev<T>(st.W0, nW, (T)1, h->stream));
+        CYMF_TRY(fill_dev<T>(st.H0, nH, (T)1, h->stream));
+    } else if (h->opt == CYMF_OPT_ADAM) {
+        CYMF_TRY(fill_dev<T>(st.W0, nW, (T)0, h->stream)); CYMF_TRY(fill_dev<T>(st.W1, nW, (T)0, h->stream));
+        CYMF_TRY(fill_dev<T>(st.H0, nH, (T)0, h->stream)); CYMF_TRY(fill_dev<T>(st.H1, nH, (T)0, h->stream));
+    }
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int cymf_relmf_upload(cymf_relmf *h, const double *W, const double *H) {
+    if (!h || !W || !H) return fail(CYMF_ERR_INVALID, "cymf_relmf_upload: bad arguments");
+    CYMF_TRY(use_device(h->device));
+    if (h->dtype == CYMF_F32) CYMF_TRY(relmf_upload(h, h->f32, W, H)); else CYMF_TRY(relmf_upload(h, h->f64, W, H));
+    h->have_params = true;
+    return 0;
+}
+
+extern "C" int cymf_relmf_download(cymf_relmf *h, double *W, double *H) {
+    if (!h || !W || !H || !h->have_params) return fail(CYMF_ERR_INVALID, "cymf_relmf_download: bad arguments / no params");
+    CYMF_TRY(use_device(h->device));
+    const size_t nW = (size_t)h->U * h->K, nH = (size_t)h->I * h->K;
+    if (h->dtype == CYMF_F32) { CYMF_TRY(download_f64(h->f32.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f32.H, H, nH, h->stream)); }
+    else { CYMF_TRY(download_f64(h->f64.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f64.H, H, nH, h->stream)); }
+    return 0;
+}
+
+extern "C" int cymf_relmf_epochs(cymf_relmf *h, int32_t n_epochs, double *loss_out) {
+    if (!h || n_epochs < 0) return fail(CYMF_ERR_INVALID, "cymf_relmf_epochs: bad arguments");
+    if (!h->have_data || !h->have_params) return fail(CYMF_ERR_INVALID, "cymf_relmf_epochs before set_data/upload");
+    CYMF_TRY(use_device(h->device));
+    for (int32_t e = 0; e < n_epochs; ++e) {
+        double *lo = loss_out ? loss_out + e : nullptr;
+        if (h->dtype == CYMF_F32) CYMF_TRY(relmf_epoch<float>(h, h->f32, lo)); else CYMF_TRY(relmf_epoch<double>(h, h->f64, lo));
+    }
+    return 0;
+}
+
+extern "C" int cymf_relmf_destroy(cymf_relmf *h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+    return 0;
+}
+
+// =====================================================================================
+//                                        GloVe
+// =====================================================================================
+template <typename T>
+struct GloveStore {
+    DevBuf<T> W, H, bW, bH, aW, aH, abW, abH, counts;
+};
+
+struct cymf_glove {
+    int32_t V = 0, Vc = 0, K = 0;
+    int dtype = 0, mode = 0, device = 0;
+    double lr = 0, x_max = 0, alpha = 0;
+    hipStream_t stream = nullptr;
+    GloveStore<float> f32;
+    GloveStore<double> f64;
+    int64_t N = 0;
+    DevBuf<int32_t> d_central, d_context;   // EXACT: level order; THROUGHPUT: given order
+    std::vector<int64_t> level_off;
+    double f_max = 1.0;                     // share of the pairs that touch the most frequent word
+    DevBuf<double> d_loss;
+    bool have_data = false, have_params = false;
+};
+
+extern "C" int cymf_glove_create(cymf_glove **out, int32_t V, int32_t Vc, int32_t K, double learning_rate, double x_max,
+                                 double alpha, int dtype, int mode, int device) {
+    if (!out) return fail(CYMF_ERR_INVALID, "cymf_glove_create: out is NULL");
+    *out = nullptr;
+    if (V <= 0 || Vc <= 0 || K <= 0) return fail(CYMF_ERR_INVALID, "cymf_glove_create: V, Vc, K must be positive");
+    if (K > 256) return fail(CYMF_ERR_UNSUPPORTED, "cymf_glove_create: K=%d > 256 is not built", K);
+    if ((dtype != CYMF_F32 && dtype != CYMF_F64) || (mode != CYMF_MODE_EXACT && mode != CYMF_MODE_THROUGHPUT))
+        return fail(CYMF_ERR_INVALID, "cymf_glove_create: bad dtype/mode");
+    CYMF_TRY(use_device(device));
+    cymf_glove *h = new cymf_glove();
+    h->V = V; h->Vc = Vc; h->K = K; h->lr = learning_rate; h->x_max = x_max; h->alpha = alpha;
+    h->dtype = dtype; h->mode = mode; h->device = device;
+    if (mode == CYMF_MODE_THROUGHPUT) {   // rows are updated from all XCDs inside one kernel: see bpr.hip
+        for (DevBuf<float> *b : {&h->f32.W, &h->f32.H, &h->f32.bW, &h->f32.bH, &h->f32.aW, &h->f32.aH, &h->f32.abW, &h->f32.abH}) b->fine = 2;
+        for (DevBuf<double> *b : {&h->f64.W, &h->f64.H, &h->f64.bW, &h->f64.bH, &h->f64.aW, &h->f64.aH, &h->f64.abW, &h->f64.abH}) b->fine = 2;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    int rc = h->d_loss.alloc(1);
+    if (rc) { (void)hipStreamDestroy(h->stream); delete h; return rc; }
+    *out = h;
+    return 0;
+}
+
+extern "C" int cymf_glove_set_data(cymf_glove *h, const int32_t *central, const int32_t *context, const double *counts,
+                                   int64_t N) {
+    if (!h || N < 0 || (N > 0 && (!central || !context || !counts))) return fail(CYMF_ERR_INVALID, "cymf_glove_set_data: bad arguments");
+    CYMF_TRY(use_device(h->device));
+    for (int64_t s = 0; s < N; ++s) {
+        // the context bias is sized like the central table (glove.pyx:94), so context < V as well
+        if (central[s] < 0 || central[s] >= h->V || context[s] < 0 || context[s] >= h->Vc || context[s] >= h->V)
+            return fail(CYMF_ERR_INVALID, "cymf_glove_set_data: pair %lld out of range", (long long)s);
+        if (!(counts[s] > 0)) return fail(CYMF_ERR_INVALID, "cymf_glove_set_data: count[%lld] must be > 0", (long long)s);
+    }
+    h->N = N;
+    {
+        std::vector<int64_t> nc((size_t)h->V, 0), nx((size_t)h->Vc, 0);
+        int64_t mx = 0;
+        for (int64_t s = 0; s < N; ++s) { mx = std::max(mx, ++nc[central[s]]); mx = std::max(mx, ++nx[context[s]]); }
+        h->f_max = N > 0 ? (double)mx / (double)N : 1.0;
+    }
+    std::vector<int32_t> c(central, central + N), x(context, context + N);
+    std::vector<double> cnt(counts, counts + N);
+    h->level_off.clear();
+    if (h->mode == CYMF_MODE_EXACT && N > 0) {   // the order is fixed for all epochs: schedule once
+        std::vector<int64_t> order;
+        level_schedule(N, central, context, h->V, h->Vc, order, h->level_off);
+        for (int64_t p = 0; p < N; ++p) { c[p] = central[order[p]]; x[p] = context[order[p]]; cnt[p] = counts[order[p]]; }
+    }
+    CYMF_TRY(h->d_central.upload(c.data(), c.size(), h->stream));
+    CYMF_TRY(h->d_context.upload(x.data(), x.size(), h->stream));
+    if (h->dtype == CYMF_F32) CYMF_TRY(upload_f64(h->f32.counts, cnt.data(), cnt.size(), h->stream));
+    else CYMF_TRY(upload_f64(h->f64.counts, cnt.data(), cnt.size(), h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    h->have_data = true;
+    return 0;
+}
+
+template <typename T>
+static int glove_upload(cymf_glove *h, GloveStore<T> &st, const double *W, const double *b, const double *Wc, const double *bc) {
+    const size_t nW = (size_t)h->V * h->K, nH = (size_t)h->Vc * h->K;
+    CYMF_TRY(upload_f64(st.W, W, nW, h->stream));
+    CYMF_TRY(upload_f64(st.bW, b, (size_t)h->V, h->stream));
+    CYMF_TRY(upload_f64(st.H, Wc, nH, h->stream));
+    CYMF_TRY(upload_f64(st.bH, bc, (size_t)h->V, h->stream));
+    CYMF_TRY(fill_dev<T>(st.aW, nW, (T)1, h->stream));
+    CYMF_TRY(fill_dev<T>(st.aH, nH, (T)1, h->stream));
+    CYMF_TRY(fill_dev<T>(st.abW, (size_t)h->V, (T)1, h->stream));
+    CYMF_TRY(fill_dev<T>(st.abH, (size_t)h->V, (T)1, h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int cymf_glove_upload(cymf_glove *h, const double *W, const double *bias, const double *Wc, const double *bias_c) {
+    if (!h || !W || !bias || !Wc || !bias_c) return fail(CYMF_ERR_INVALID, "cymf_glove_upload: bad arguments");
+    CYMF_TRY(use_device(h->device));
+    if (h->dtype == CYMF_F32) CYMF_TRY(glove_upload(h, h->f32, W, bias, Wc, bias_c));
+    else CYMF_TRY(glove_upload(h, h->f64, W, bias, Wc, bias_c));
+    h->have_params = true;
+    return 0;
+}
+
+extern "C" int cymf_glove_download(cymf_glove *h, double *W, double *bias, double *Wc, double *bias_c) {
+    if (!h || !W || !bias || !Wc || !bias_c || !h->have_params) return fail(CYMF_ERR_INVALID, "cymf_glove_download: bad arguments / no params");
+    CYMF_TRY(use_device(h->device));
+    const size_t nW = (size_t)h->V * h->K, nH = (size_t)h->Vc * h->K;
+    if (h->dtype == CYMF_F32) {
+        CYMF_TRY(download_f64(h->f32.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f32.bW, bias, (size_t)h->V, h->stream));
+        CYMF_TRY(download_f64(h->f32.H, Wc, nH, h->stream)); CYMF_TRY(download_f64(h->f32.bH, bias_c, (size_t)h->V, h->stream));
+    } else {
+        CYMF_TRY(download_f64(h->f64.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f64.bW, bias, (size_t)h->V, h->stream));
+        CYMF_TRY(download_f64(h->f64.H, Wc, nH, h->stream)); CYMF_TRY(download_f64(h->f64.bH, bias_c, (size_t)h->V, h->stream));
+    }
+    return 0;
+}
+
+template <typename T>
+static int glove_epoch(cymf_glove *h, GloveStore<T> &st, double *loss_out) {
+    GloveDev<T> d;
+    d.W = st.W.p; d.H = st.H.p; d.bW = st.bW.p; d.bH = st.bH.p;
+    d.aW = st.aW.p; d.aH = st.aH.p; d.abW = st.abW.p; d.abH = st.abH.p;
+    d.K = h->K; d.lr = (T)h->lr; d.x_max = (T)h->x_max; d.alpha = (T)h->alpha;
+    CYMF_TRY(h->d_loss.zero(h->stream));
+    if (h->N > 0) {
+        if (h->mode == CYMF_MODE_THROUGHPUT) {
+            launch_glove<T>(h->K, d, h->d_central.p, h->d_context.p, st.counts.p, h->N, h->d_loss.p, hogwild_grid(h->N, h->f_max), h->stream);
+        } else {
+            for (size_t lv = 1; lv + 1 < h->level_off.size(); ++lv) {
+                const int64_t b = h->level_off[lv], n = h->level_off[lv + 1] - b;
+                if (n > 0) launch_glove<T>(h->K, d, h->d_central.p + b, h->d_context.p + b, st.counts.p + b, n, h->d_loss.p, (int)((n + 3) / 4), h->stream);
+            }
+        }
+        CYMF_HIP(hipGetLastError());
+    }
+    double loss = 0;
+    CYMF_HIP(hipMemcpyAsync(&loss, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    if (loss_out) *loss_out = loss;
+    return 0;
+}
+
+extern "C" int cymf_glove_epochs(cymf_glove *h, int32_t n_epochs, double *loss_out) {
+    if (!h || n_epochs < 0) return fail(CYMF_ERR_INVALID, "cymf_glove_epochs: bad arguments");
+    if (!h->have_data || !h->have_params) return fail(CYMF_ERR_INVALID, "cymf_glove_epochs before set_data/upload");
+    CYMF_TRY(use_device(h->device));
+    for (int32_t e = 0; e < n_epochs; ++e) {
+        double *lo = loss_out ? loss_out + e : nullptr;
+        if (h->dtype == CYMF_F32) CYMF_TRY(glove_epoch<float>(h, h->f32, lo)); else CYMF_TRY(glove_epoch<double>(h, h->f64, lo));
+    }
+    return 0;
+}
+
+extern "C" int cymf_glove_destroy(cymf_glove *h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    delete h;
+    return 0;
+}

@@ -1,0 +1,101 @@
+"""One process per GPU: RCCL communicator over xGMI + user-range sharding.
+
+The reference is single-process; this is the only exchange step the user-sharded design adds
+(sum of item-factor deltas after every step).  Rendezvous is a file in /tmp keyed by
+MASTER_PORT (single node, as launched by `python -m torch.distributed.run --nnodes=1 ...`,
+whose env vars RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT are read) -- no torch import."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def user_shards(indptr, world):
+    """Contiguous user ranges balanced by nnz: [(lo, hi)] * world."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    U = len(indptr) - 1
+    nnz = indptr[-1]
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(indptr, nnz * r // world, side="left")))
+    cuts.append(U)
+    cuts = np.maximum.accumulate(np.minimum(cuts, U))
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
+
+
+class Comm:
+    """RCCL communicator handle (cymf_comm_*)."""
+
+    def __init__(self, rank, world, device, unique_id):
+        self.L = _lib.lib()
+        self.rank, self.world, self.device = rank, world, device
+        self.h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
+        _lib.check(self.L.cymf_comm_create(C.byref(self.h), buf, rank, world, device))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        _lib.check(_lib.lib().cymf_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_env(cls, device=None, timeout=300.0):
+        rank, world, local = env_rank_world()
+        device = local if device is None else device
+        port = os.environ.get("MASTER_PORT", "0")
+        run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+        path = f"/tmp/cymf_amd_rdzv_{port}_{run}_{world}"
+        if rank == 0:
+            uid = cls.unique_id()
+            tmp = path + f".{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    # only accept a file written after this process started looking (stale files of an
+                    # earlier run with the same port are replaced by rank 0 first)
+                    if os.path.exists(path) and os.path.getmtime(path) >= _START - 120:
+                        with open(path, "rb") as f:
+                            uid = f.read()
+                        if len(uid) == _lib.UNIQUE_ID_BYTES:
+                            break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout:
+                    raise TimeoutError("cymf_amd.dist: rendezvous file never appeared")
+                time.sleep(0.05)
+        c = cls(rank, world, device, uid)
+        c._rdzv_path = path
+        return c
+
+    def allreduce(self, arr, op="sum"):
+        a = np.ascontiguousarray(arr, dtype=np.float32).copy()
+        _lib.check(self.L.cymf_comm_allreduce_f32(self.h, _lib.ptr(a), a.size, 1 if op == "max" else 0))
+        return a
+
+    def barrier(self):
+        self.allreduce(np.zeros(1, dtype=np.float32))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.cymf_comm_destroy(self.h)
+            self.h = None
+            if self.rank == 0 and getattr(self, "_rdzv_path", None):
+                try:
+                    os.remove(self._rdzv_path)
+                except OSError:
+                    pass
+
+
+_START = time.time()

@@ -56,6 +56,52 @@ def implicit_matrix(U, I, nnz, seed, zipf_s=1.0, sigma=1.0, oversample=1.08, max
     return X
 
 
+def implicit_matrix_large(U, I, nnz, seed, zipf_s=1.0, sigma=1.0, oversample=1.06):
+    """Same distribution as implicit_matrix, organised for 1e7..1e9 interactions: per-user counts
+    are drawn first (multinomial over the lognormal activities), so the (user, item) keys are
+    generated already grouped by user and one sort of the int64 keys de-duplicates them.
+    Returns ~nnz interactions (a little fewer than requested after de-duplication is possible)."""
+    rng = np.random.default_rng(seed)
+    act = rng.lognormal(mean=0.0, sigma=sigma, size=U)
+    act /= act.sum()
+    pop = 1.0 / np.arange(1, I + 1, dtype=np.float64) ** zipf_s
+    cdf_i = np.cumsum(pop / pop.sum())
+    cdf_i[-1] = 1.0
+    perm = rng.permutation(I).astype(np.int64)
+    keys = np.empty(0, dtype=np.int64)
+    need = nnz
+    for _ in range(8):
+        m = int(need * oversample) + 1024
+        n_u = np.minimum(rng.multinomial(m, act), I)
+        new = np.repeat(np.arange(U, dtype=np.int64) * I, n_u)
+        block = 1 << 24
+        for b in range(0, len(new), block):     # bounded temporaries
+            e = min(b + block, len(new))
+            new[b:e] += perm[np.searchsorted(cdf_i, rng.random(e - b), side="right")]
+        keys = np.concatenate([keys, new]) if len(keys) else new
+        del new
+        keys.sort()
+        keep = np.ones(len(keys), dtype=bool)
+        keep[1:] = keys[1:] != keys[:-1]
+        keys = keys[keep]
+        if len(keys) >= nnz:
+            break
+        need = nnz - len(keys)
+        oversample = max(oversample, 1.6)
+    if len(keys) > nnz:
+        drop = rng.choice(len(keys), size=len(keys) - nnz, replace=False)
+        keep = np.ones(len(keys), dtype=bool)
+        keep[drop] = False
+        keys = keys[keep]
+    rows = (keys // I).astype(np.int32)
+    cols = (keys % I).astype(np.int32)
+    del keys
+    indptr = np.zeros(U + 1, dtype=np.int64)
+    indptr[1:] = np.bincount(rows, minlength=U)
+    indptr = np.cumsum(indptr)
+    return rows, cols, indptr
+
+
 def config_matrix(name):
     U, I, nnz, K, seed = CONFIGS[name]
     return implicit_matrix(U, I, nnz, seed), K

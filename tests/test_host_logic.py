@@ -1,0 +1,151 @@
+"""Host-side mirror of the reference's class surface: argument validation,
+initialisation / shuffle parity, sharding helpers, metrics, co-occurrence builder.  CPU only."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle
+from conftest import golden
+from cymf_amd import BPR, WMF, GloVe, RelMF, _host, dist, metrics, synthetic
+from cymf_amd.glove import read_text
+
+
+def test_constructor_defaults_match_reference():
+    m = BPR()
+    assert (m.num_components, m.learning_rate, m.optimizer, m.weight_decay) == (20, 0.001, "adam", 0.01)
+    assert m.W is None and m.H is None
+    w = WMF()
+    assert (w.num_components, w.weight_decay, w.weight) == (20, 0.01, 10.0)
+    g = GloVe()
+    assert (g.num_components, g.learning_rate, g.alpha, g.x_max) == (50, 0.01, 0.75, 10.0)
+    r = RelMF()
+    assert (r.num_components, r.clip_value, r.learning_rate, r.optimizer, r.weight_decay) == (20, 0.1, 0.001, "adam", 0.01)
+
+
+def test_invalid_optimizer_raises_like_reference():
+    with pytest.raises(Exception, match="rmsprop is invalid."):
+        BPR(optimizer="rmsprop")
+    with pytest.raises(Exception, match="x is invalid."):
+        RelMF(optimizer="x")
+
+
+def test_fit_argument_errors():
+    X = sparse.csr_matrix(np.eye(3))
+    for cls in (BPR, WMF):
+        with pytest.raises(ValueError):
+            cls().fit(None)
+        with pytest.raises(ValueError):
+            cls().fit([[1, 0], [0, 1]])
+        with pytest.raises(ValueError):
+            cls().fit(X, early_stopping=True)            # no evaluator
+    with pytest.raises(ValueError):
+        RelMF().fit(None)
+    with pytest.raises(ValueError):
+        GloVe().fit(None, 1, 1)
+    with pytest.raises(TypeError):
+        GloVe().fit(np.eye(3), 1, 1)                      # dense is rejected (glove.pyx:88-89)
+
+
+def test_init_and_shuffle_match_reference_semantics():
+    class M:
+        W = None
+        H = None
+    m = M()
+    _host.init_factors(m, 7, 9, 4)
+    users, pos = _host.reference_shuffle(np.arange(20), np.arange(20) * 2)
+    W, H = oracle.reference_init(7, 9, 4)
+    u2, p2 = oracle.reference_shuffle(np.arange(20), np.arange(20) * 2)
+    assert np.array_equal(m.W, W) and np.array_equal(m.H, H)
+    assert np.array_equal(users, u2) and np.array_equal(pos, p2)
+    # equals sklearn.utils.shuffle on the same global state (cymf/bpr.pyx:104)
+    sk = pytest.importorskip("sklearn.utils")
+    np.random.seed(99)
+    a, b = sk.shuffle(np.arange(50), np.arange(50) + 100)
+    np.random.seed(99)
+    c, d = _host.reference_shuffle(np.arange(50), np.arange(50) + 100)
+    assert np.array_equal(a, c) and np.array_equal(b, d)
+
+
+def test_preset_H_only_draws_W_after_seed():
+    class M:
+        W = None
+        H = np.ones((5, 3))
+    m = M()
+    _host.init_factors(m, 4, 5, 3)
+    np.random.seed(4321)
+    W = np.random.uniform(-0.1, 0.1, (4, 3)) / 3
+    assert np.array_equal(m.W, W) and np.array_equal(m.H, np.ones((5, 3)))
+
+
+def test_membership_pattern_drops_zeros_and_sorts():
+    X = sparse.csr_matrix((np.array([1.0, 0.0, 2.0, 1.0]), np.array([3, 1, 0, 2]), np.array([0, 3, 4])), shape=(2, 4))
+    indptr, indices = _host.membership_pattern(X)
+    assert indptr.tolist() == [0, 2, 3] and indices.tolist() == [0, 3, 2]
+
+
+def test_pick_mode():
+    assert _host.pick_mode(None, 1) == "exact"
+    assert _host.pick_mode(None, 8) == "throughput" and _host.pick_mode(None, 0) == "throughput"
+    assert _host.pick_mode("exact", 8) == "exact"
+    with pytest.raises(ValueError):
+        _host.pick_mode("fast", 1)
+
+
+def test_user_shards_cover_and_balance():
+    X = synthetic.implicit_matrix(5000, 800, 60000, 1)
+    for world in (1, 2, 3, 8):
+        sh = dist.user_shards(X.indptr, world)
+        assert sh[0][0] == 0 and sh[-1][1] == 5000
+        assert all(sh[r][1] == sh[r + 1][0] for r in range(world - 1))
+        loads = [X.indptr[hi] - X.indptr[lo] for lo, hi in sh]
+        assert sum(loads) == X.nnz
+        assert max(loads) <= X.nnz / world + X.getnnz(axis=1).max()
+
+
+def test_metrics_match_reference_fixture_and_oracle():
+    g = golden("metrics")
+    for r, y in enumerate(g["y"]):
+        for c, k in enumerate(g["ks"]):
+            k = int(k)
+            assert metrics.dcg_at_k(y, k) == pytest.approx(g["dcg"][r, c], rel=1e-14, abs=0)
+            assert metrics.recall_at_k(y, k) == pytest.approx(g["recall"][r, c], rel=1e-14, abs=0)
+            assert metrics.average_precision_at_k(y, k) == pytest.approx(g["ap"][r, c], rel=1e-14, abs=0)
+    # IPS variants reduce to the plain ones at unit propensity
+    rs = np.random.RandomState(0)
+    y = (rs.rand(40) < 0.2).astype(np.int32)
+    p = np.ones(40)
+    assert metrics.dcg_at_k_with_ips(y, p, 5) == pytest.approx(oracle.dcg_at_k(y, 5))
+    assert metrics.recall_at_k_with_ips(y, p, 5) == pytest.approx(oracle.recall_at_k(y, 5))
+    assert metrics.average_precision_at_k_with_ips(y, p, 5) == pytest.approx(oracle.ap_at_k(y, 5))
+
+
+def test_read_text_matches_reference_loop(tmp_path):
+    rs = np.random.RandomState(1)
+    vocab = [f"w{i}" for i in range(30)]
+    words = [vocab[min(int(abs(rs.normal()) * 8), 29)] for _ in range(400)]
+    f = tmp_path / "corpus.txt"
+    f.write_text(" ".join(words))
+    M, i2w = read_text(str(f), min_count=3, window_size=4)
+    # straight restatement of cymf/glove.pyx:199-241 (single line of text, as text8 is)
+    from collections import Counter
+    cnt = Counter(words)
+    w2i, ids = {}, []
+    for w in words:
+        if cnt[w] >= 3:
+            w2i.setdefault(w, len(w2i))
+            ids.append(w2i[w])
+    V = len(w2i)
+    D = np.zeros((V, V))
+    for j in range(len(ids)):
+        for k in range(max(0, j - 4), j):
+            D[ids[j], ids[k]] += 1.0 / abs(j - k)
+    assert M.shape == (V, V) and np.allclose(M.toarray(), D, rtol=1e-13, atol=0)
+    assert [i2w[i] for i in range(V)] == list(w2i)
+
+
+def test_synthetic_configs_have_the_stated_shape():
+    X, K = synthetic.config_matrix("C1")
+    assert X.shape == (943, 1682) and X.nnz == 44853 and K == 20
+    assert X.has_sorted_indices and (X.data == 1.0).all()
+    X2, _ = synthetic.config_matrix("C1")
+    assert (X != X2).nnz == 0   # deterministic
