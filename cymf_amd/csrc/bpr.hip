@@ -839,7 +839,8 @@ extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_
     CYMF_TRY(h->d_indices.upload(h->h_indices.data(), h->h_indices.size(), h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
     if (!h->rng_ready) {   // ONE generator for the whole fit (bpr.pyx:141)
-        CYMF_TRY(h->rng.init(h->seed, (uint64_t)h->I, h->rng_stream));
+        // >= 2M draws per epoch: chunked jump-ahead generator (rng.hip), else the one-workgroup walker
+        CYMF_TRY(h->rng.init(h->seed, (uint64_t)h->I, h->rng_stream, /*parallel=*/N_global >= (int64_t)2 << 20));
         h->rng_ready = true;
     }
     if (h->mode == CYMF_MODE_THROUGHPUT) CYMF_TRY(build_throughput_layout(h));

@@ -14,17 +14,42 @@ struct RngState {
 };
 
 // One stream = one generator created once and never reseeded (cymf/bpr.pyx:141).
+//   serial mode   : one workgroup walks the stream (small problems, high-rejection ranges).
+//   parallel mode : the raw stream is cut into chunks of MT_JUMP_WORDS words; chunk start states
+//                   come from the jump-ahead polynomial (mt_jump_poly.h), one workgroup per chunk
+//                   generates and compacts its accepted words, a last pass gathers them in order.
 class DeviceRng {
   public:
-    // range in [1, 2^32-1]
-    int init(uint32_t seed, uint64_t range, hipStream_t s);
-    // Discards n_skip draws, then writes the next n draws to d_out[0..n) (device pointer).
+    ~DeviceRng();
+    // range in [1, 2^32-1]; parallel = use the chunked generator (falls back to serial when the
+    // Lemire rejection rate of `range` is too high for its per-chunk rejection list)
+    int init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel = false);
+    // Discards n_skip draws, then writes the next n draws to d_out[0..n) (device pointer), in
+    // stream order on `s`.  Asynchronous; the stream position is settled lazily (finalize).
     int generate(int64_t n_skip, int64_t n, uint32_t *d_out, hipStream_t s);
     uint64_t range() const { return range_; }
+    bool parallel() const { return parallel_; }
 
   private:
+    int generate_parallel(int64_t n_total, int64_t n_skip, uint32_t *d_out, hipStream_t s);
+    int finalize();   // host: wait for the last parallel launch and advance raw_pos_
+    int ensure_states(int64_t last_chunk, hipStream_t s);
+
     DevBuf<RngState> st_;
     uint32_t range_ = 0, thr_ = 0;
+    bool parallel_ = false;
+    // parallel mode
+    uint64_t raw_pos_ = 0;              // next unconsumed raw word of the stream
+    DevBuf<uint32_t> poly_, states_, tmp_, counts_, rej_, rej_cnt_;
+    int64_t states_cap_ = 0, states_known_ = 0;   // chunk start states [0, states_known_) are valid
+    struct Pending {
+        bool active = false;
+        hipEvent_t done = nullptr;
+        uint32_t *h_counts = nullptr, *h_rej = nullptr, *h_rej_cnt = nullptr;   // pinned
+        int64_t cap_chunks = 0;
+        int64_t c0 = 0, n_chunks = 0, n_total = 0;
+        uint64_t skip0 = 0;
+    } pend_;
 };
 
 }  // namespace cymf

@@ -9,6 +9,10 @@
 // the fast path with no prefix scan).
 #include "rng.h"
 
+#include <algorithm>
+
+#include "mt_jump_poly.h"
+
 namespace cymf {
 
 namespace {
@@ -154,6 +158,149 @@ __global__ __launch_bounds__(RNG_THREADS) void rng_generate_kernel(RngState *st,
     }
 }
 
+// ---------------------------------------------------------------- parallel mode
+// Jump ahead by J = MT_JUMP_WORDS raw words: state(n+J) = XOR over the set bits k of g of
+// state(n+k), evaluated on the recurrence's own word sequence x (x_0..x_623 = state):
+// out[m] = XOR_k g_k x[k+m].  The 624 + 19937 words live in LDS (82 KB).
+constexpr int JUMP_THREADS = 1024;
+constexpr int JUMP_DEG = 19937;
+constexpr int JUMP_LDS_WORDS = MT_N + JUMP_DEG + 3;
+
+__global__ __launch_bounds__(JUMP_THREADS) void mt_jump_kernel(const uint32_t *__restrict__ in_state,
+                                                              uint32_t *__restrict__ out_state,
+                                                              const uint32_t *__restrict__ poly) {
+    extern __shared__ uint32_t x[];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < MT_N; k += JUMP_THREADS) x[k] = in_state[k];
+    __syncthreads();
+    for (int b = 0; b < JUMP_DEG; b += 227) {     // lag 227: one data-parallel slab per barrier
+        const int k = b + tid;
+        if (tid < 227 && k < JUMP_DEG) x[k + MT_N] = x[k + MT_M] ^ mt_mix(x[k], x[k + 1]);
+        __syncthreads();
+    }
+    if (tid < MT_N) {
+        uint32_t acc = 0;
+        for (int w = 0; w < MT_N; ++w) {
+            uint32_t bits = poly[w];              // wave-uniform
+            const int base = w * 32 + tid;
+            while (bits) {
+                const int k = __builtin_ctz(bits);
+                bits &= bits - 1;
+                acc ^= x[base + k];
+            }
+        }
+        out_state[tid] = acc;
+    }
+}
+
+constexpr int REJ_CAP = 8192;   // recorded rejection offsets per chunk
+
+// Workgroup q generates chunk (c0 + q) of the raw stream from its start state and writes the
+// accepted words (Lemire) compacted to tmp[q*J ...]; words before skip0 belong to an earlier call
+// (chunk 0 only).  Rejected raw offsets are recorded so that the host can settle the stream position.
+__global__ __launch_bounds__(RNG_THREADS) void rng_chunk_kernel(const uint32_t *__restrict__ states, uint32_t skip0,
+                                                               uint32_t range, uint32_t thr,
+                                                               uint32_t *__restrict__ tmp, uint32_t *__restrict__ counts,
+                                                               uint32_t *__restrict__ rej, uint32_t *__restrict__ rej_cnt) {
+    __shared__ uint32_t buf[2][MT_N];
+    __shared__ int s_wcnt[RNG_THREADS / 64];
+    __shared__ uint32_t s_nrej;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const uint32_t first = q == 0 ? skip0 : 0u;
+    uint32_t *__restrict__ out = tmp + (size_t)q * MT_JUMP_WORDS;
+    uint32_t *__restrict__ myrej = rej + (size_t)q * REJ_CAP;
+    for (int k = tid; k < MT_N; k += RNG_THREADS) buf[0][k] = states[(size_t)q * MT_N + k];
+    if (tid == 0) s_nrej = 0;
+    int cur = 0;
+    uint32_t base = 0;   // accepted so far (uniform)
+    __syncthreads();
+    for (int blk = 0; blk < MT_JUMP_BLOCKS; ++blk) {
+        const uint32_t *c = buf[cur];
+        uint32_t *nx = buf[cur ^ 1];
+        if (tid < 227) nx[tid] = c[tid + MT_M] ^ mt_mix(c[tid], c[tid + 1]);
+        __syncthreads();
+        if (tid < 227) { int k = tid + 227; nx[k] = nx[k - 227] ^ mt_mix(c[k], c[k + 1]); }
+        __syncthreads();
+        if (tid < 170) { int k = tid + 454; nx[k] = nx[k - 227] ^ mt_mix(c[k], k == MT_N - 1 ? nx[0] : c[k + 1]); }
+        __syncthreads();
+        cur ^= 1;
+        const uint32_t off0 = (uint32_t)blk * MT_N;
+        if (off0 + MT_N <= first) continue;        // whole block consumed by an earlier call (uniform)
+        const uint32_t *g = buf[cur];
+        uint32_t val[3];
+        bool ok[3];
+        bool special = false;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t w = tid + RNG_THREADS * r;
+            const bool have = w < MT_N;
+            const uint64_t p = (uint64_t)mt_temper(have ? g[w] : 0u) * (uint64_t)range;
+            val[r] = (uint32_t)(p >> 32);
+            const bool live = have && off0 + w >= first;
+            const bool acc = (uint32_t)p >= thr;
+            ok[r] = live && acc;
+            special |= have && !ok[r];
+            if (live && !acc) {
+                const uint32_t slot = atomicAdd(&s_nrej, 1u);
+                if (slot < REJ_CAP) myrej[slot] = off0 + w;
+            }
+        }
+        if (!__syncthreads_or(special)) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const uint32_t w = tid + RNG_THREADS * r;
+                if (w < MT_N) out[base + w] = val[r];
+            }
+            base += MT_N;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const unsigned long long m = __ballot(ok[r]);
+                const int lane_pre = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == 0) s_wcnt[wave] = __popcll(m);
+                __syncthreads();
+                int wave_off = 0, total = 0;
+#pragma unroll
+                for (int v = 0; v < RNG_THREADS / 64; ++v) {
+                    const int cnt = s_wcnt[v];
+                    if (v < wave) wave_off += cnt;
+                    total += cnt;
+                }
+                if (ok[r]) out[base + wave_off + lane_pre] = val[r];
+                base += total;
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        counts[q] = base;
+        rej_cnt[q] = s_nrej;
+    }
+}
+
+// out[d - n_skip] = d-th accepted word over the chunks, for d in [n_skip, n_total)
+__global__ __launch_bounds__(256) void rng_gather_kernel(const uint32_t *__restrict__ tmp, const uint32_t *__restrict__ counts,
+                                                        int n_chunks, int64_t n_skip, int64_t n_total,
+                                                        uint32_t *__restrict__ out) {
+    __shared__ int64_t s_prefix;
+    const int q = blockIdx.y;
+    if (threadIdx.x == 0) {
+        int64_t p = 0;
+        for (int v = 0; v < q; ++v) p += counts[v];
+        s_prefix = p;
+    }
+    __syncthreads();
+    const int64_t prefix = s_prefix;
+    const int64_t cnt = counts[q];
+    const uint32_t *__restrict__ src = tmp + (size_t)q * MT_JUMP_WORDS;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < cnt; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = prefix + r;
+        if (d >= n_skip && d < n_total) out[d - n_skip] = src[r];
+    }
+}
+
 __global__ void widen_u32_i64_kernel(const uint32_t *__restrict__ in, int64_t *__restrict__ out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -162,7 +309,14 @@ __global__ void widen_u32_i64_kernel(const uint32_t *__restrict__ in, int64_t *_
 
 }  // namespace
 
-int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s) {
+DeviceRng::~DeviceRng() {
+    if (pend_.done) (void)hipEventDestroy(pend_.done);
+    if (pend_.h_counts) (void)hipHostFree(pend_.h_counts);
+    if (pend_.h_rej) (void)hipHostFree(pend_.h_rej);
+    if (pend_.h_rej_cnt) (void)hipHostFree(pend_.h_rej_cnt);
+}
+
+int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel) {
     if (range < 1 || range > 0xffffffffull)
         return fail(CYMF_ERR_UNSUPPORTED,
                     "index stream range %llu outside [1, 2^32-1] (the reference densifies X for RelMF, "
@@ -172,6 +326,109 @@ int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s) {
     thr_ = (uint32_t)(0u - range_) % range_;   // (2^32 - range) mod range, bits/uniform_int_dist.h:260
     hipLaunchKernelGGL(rng_seed_kernel, dim3(1), dim3(64), 0, s, st_.p, seed);
     CYMF_HIP(hipGetLastError());
+    // the per-chunk rejection list must hold the expected rejections with a wide margin
+    const double rej_per_chunk = (double)thr_ / 4294967296.0 * (double)MT_JUMP_WORDS;
+    parallel_ = parallel && rej_per_chunk * 8.0 + 64.0 < (double)REJ_CAP;
+    if (parallel_) {
+        CYMF_TRY(poly_.upload(MT_JUMP_POLY, MT_N, s));
+        states_cap_ = 64;
+        CYMF_TRY(states_.alloc((size_t)states_cap_ * MT_N));
+        // chunk 0 starts at the seeded state (RngState begins with mt[624])
+        CYMF_HIP(hipMemcpyAsync(states_.p, st_.p, MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        states_known_ = 1;
+        raw_pos_ = 0;
+        CYMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(JUMP_LDS_WORDS * sizeof(uint32_t))));
+        if (!pend_.done) CYMF_HIP(hipEventCreateWithFlags(&pend_.done, hipEventDisableTiming));
+    }
+    return 0;
+}
+
+int DeviceRng::ensure_states(int64_t last_chunk, hipStream_t s) {
+    if (last_chunk + 1 > states_cap_) {
+        int64_t cap = states_cap_;
+        while (cap < last_chunk + 1) cap *= 2;
+        DevBuf<uint32_t> bigger;
+        CYMF_TRY(bigger.alloc((size_t)cap * MT_N));
+        CYMF_HIP(hipMemcpyAsync(bigger.p, states_.p, (size_t)states_known_ * MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        CYMF_HIP(hipStreamSynchronize(s));
+        std::swap(bigger.p, states_.p);
+        std::swap(bigger.n, states_.n);
+        states_cap_ = cap;
+    }
+    while (states_known_ <= last_chunk) {   // chain of jumps, each ~0.1 ms on one CU
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(1), dim3(JUMP_THREADS), JUMP_LDS_WORDS * sizeof(uint32_t), s,
+                           states_.p + (size_t)(states_known_ - 1) * MT_N, states_.p + (size_t)states_known_ * MT_N, poly_.p);
+        CYMF_HIP(hipGetLastError());
+        states_known_++;
+    }
+    return 0;
+}
+
+int DeviceRng::finalize() {
+    if (!pend_.active) return 0;
+    CYMF_HIP(hipEventSynchronize(pend_.done));
+    pend_.active = false;
+    int64_t prefix = 0;
+    for (int64_t q = 0; q < pend_.n_chunks; ++q) {
+        const int64_t cnt = pend_.h_counts[q];
+        if (pend_.h_rej_cnt[q] > (uint32_t)REJ_CAP)
+            return fail(CYMF_ERR_UNSUPPORTED, "index stream: %u rejections in one chunk exceed the parallel generator's list",
+                        pend_.h_rej_cnt[q]);
+        if (prefix + cnt >= pend_.n_total) {
+            // the last requested draw is the accepted word of rank r in chunk q: its raw offset is
+            // r (+ skip0 in chunk 0) plus the rejected words at or before it
+            const int64_t r = pend_.n_total - 1 - prefix;
+            uint64_t pos = (uint64_t)r + (q == 0 ? pend_.skip0 : 0);
+            uint32_t *lst = pend_.h_rej + (size_t)q * REJ_CAP;
+            const uint32_t nr = pend_.h_rej_cnt[q];
+            std::sort(lst, lst + nr);
+            for (uint32_t i = 0; i < nr && (uint64_t)lst[i] <= pos; ++i) ++pos;
+            raw_pos_ = (uint64_t)(pend_.c0 + q) * (uint64_t)MT_JUMP_WORDS + pos + 1;
+            return 0;
+        }
+        prefix += cnt;
+    }
+    return fail(CYMF_ERR_HIP, "index stream: chunked generator produced %lld of %lld draws", (long long)prefix,
+                (long long)pend_.n_total);
+}
+
+int DeviceRng::generate_parallel(int64_t n_total, int64_t n_skip, uint32_t *d_out, hipStream_t s) {
+    CYMF_TRY(finalize());
+    const int64_t J = MT_JUMP_WORDS;
+    const int64_t c0 = (int64_t)(raw_pos_ / (uint64_t)J);
+    const uint64_t skip0 = raw_pos_ % (uint64_t)J;
+    const double p_rej = (double)thr_ / 4294967296.0;
+    const int64_t need_raw = n_total + (int64_t)((double)n_total * p_rej * 1.5) + 4096;
+    const int64_t n_chunks = ((int64_t)skip0 + need_raw + J - 1) / J;
+    CYMF_TRY(ensure_states(c0 + n_chunks - 1, s));
+    CYMF_TRY(tmp_.alloc((size_t)n_chunks * (size_t)J));
+    if (n_chunks > pend_.cap_chunks) {
+        if (pend_.h_counts) (void)hipHostFree(pend_.h_counts);
+        if (pend_.h_rej) (void)hipHostFree(pend_.h_rej);
+        if (pend_.h_rej_cnt) (void)hipHostFree(pend_.h_rej_cnt);
+        pend_.cap_chunks = n_chunks * 2;
+        CYMF_HIP(hipHostMalloc((void **)&pend_.h_counts, (size_t)pend_.cap_chunks * sizeof(uint32_t)));
+        CYMF_HIP(hipHostMalloc((void **)&pend_.h_rej_cnt, (size_t)pend_.cap_chunks * sizeof(uint32_t)));
+        CYMF_HIP(hipHostMalloc((void **)&pend_.h_rej, (size_t)pend_.cap_chunks * REJ_CAP * sizeof(uint32_t)));
+        CYMF_TRY(counts_.alloc((size_t)pend_.cap_chunks));
+        CYMF_TRY(rej_cnt_.alloc((size_t)pend_.cap_chunks));
+        CYMF_TRY(rej_.alloc((size_t)pend_.cap_chunks * REJ_CAP));
+    }
+    hipLaunchKernelGGL(rng_chunk_kernel, dim3((unsigned)n_chunks), dim3(RNG_THREADS), 0, s, states_.p + (size_t)c0 * MT_N,
+                       (uint32_t)skip0, range_, thr_, tmp_.p, counts_.p, rej_.p, rej_cnt_.p);
+    CYMF_HIP(hipGetLastError());
+    if (d_out && n_total > n_skip) {
+        hipLaunchKernelGGL(rng_gather_kernel, dim3(64, (unsigned)n_chunks), dim3(256), 0, s, tmp_.p, counts_.p, (int)n_chunks,
+                           n_skip, n_total, d_out);
+        CYMF_HIP(hipGetLastError());
+    }
+    CYMF_HIP(hipMemcpyAsync(pend_.h_counts, counts_.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CYMF_HIP(hipMemcpyAsync(pend_.h_rej_cnt, rej_cnt_.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CYMF_HIP(hipMemcpyAsync(pend_.h_rej, rej_.p, (size_t)n_chunks * REJ_CAP * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CYMF_HIP(hipEventRecord(pend_.done, s));
+    pend_.active = true;
+    pend_.c0 = c0; pend_.n_chunks = n_chunks; pend_.n_total = n_total; pend_.skip0 = skip0;
     return 0;
 }
 
@@ -179,6 +436,7 @@ int DeviceRng::generate(int64_t n_skip, int64_t n, uint32_t *d_out, hipStream_t 
     if (!st_.p) return fail(CYMF_ERR_INVALID, "DeviceRng::generate before init");
     if (n_skip < 0 || n < 0) return fail(CYMF_ERR_INVALID, "negative draw count");
     if (n_skip + n == 0) return 0;
+    if (parallel_) return generate_parallel(n_skip + n, n_skip, d_out, s);
     hipLaunchKernelGGL(rng_generate_kernel, dim3(1), dim3(RNG_THREADS), 0, s, st_.p, range_, thr_, n_skip, n, d_out);
     CYMF_HIP(hipGetLastError());
     return 0;
@@ -193,7 +451,7 @@ extern "C" int cymf_rng_fill_uniform(int device, uint32_t seed, uint64_t range, 
     if (n < 0 || skip < 0 || (n > 0 && !out)) return fail(CYMF_ERR_INVALID, "cymf_rng_fill_uniform: bad arguments");
     CYMF_TRY(use_device(device));
     DeviceRng rng;
-    CYMF_TRY(rng.init(seed, range, nullptr));
+    CYMF_TRY(rng.init(seed, range, nullptr, /*parallel=*/skip + n >= (int64_t)4 << 20));
     if (n == 0) return 0;
     DevBuf<uint32_t> d32;
     DevBuf<int64_t> d64;

@@ -50,3 +50,14 @@ def test_range_limits_are_errors():
     with pytest.raises(_lib.CymfError):
         _lib.rng_fill_uniform(1234, 0, 10)
     assert len(_lib.rng_fill_uniform(1234, 10, 0)) == 0
+
+
+@pytest.mark.parametrize("rng_range,n,skip", [(100000, 9_000_000, 0), (100000, 200_000, 4_193_280 * 2 - 100_000),
+                                              (3706, 5_000_000, 4_193_279), (40_000_000, 6_000_000, 11)])
+def test_chunked_jump_ahead_generator_vs_oracle(rng_range, n, skip):
+    """skip + n >= 4M selects the parallel generator: chunk start states by the MT19937 jump-ahead
+    polynomial (tools/gen_mt_jump.py), one workgroup per 4,193,280-word chunk, ordered gather.
+    range 4e7 rejects ~1% of the raw words (hundreds of rejections per chunk boundary case)."""
+    got = _lib.rng_fill_uniform(1234, rng_range, n, skip=skip)
+    want = oracle.uniform_stream(1234, rng_range, n, skip=skip)
+    assert np.array_equal(got, want)
