@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void bpr_sample_kernel(const int32_t *__restri
                                                         const uint32_t *__restrict__ draws,
                                                         const int32_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices,
+                                                        const uint32_t *__restrict__ hot_bits,
                                                         int32_t *__restrict__ slot_neg, int64_t n,
                                                         unsigned long long *__restrict__ skipped) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,7 +124,10 @@ __global__ __launch_bounds__(256) void bpr_sample_kernel(const int32_t *__restri
             if (v == j) { found = true; break; }
             if (v < j) lo = mid + 1; else hi = mid;
         }
-        slot_neg[t] = found ? -1 : j;
+        // bit 30 marks a negative that is a HOT item (many positive-side exchanges per step): the step
+        // kernel adds its delta atomically instead of storing the row back
+        const int32_t hot = (int32_t)((hot_bits[j >> 5] >> (j & 31)) & 1u) << 30;
+        slot_neg[t] = found ? -1 : (j | hot);
         my_skips += found ? 1u : 0u;
     }
     // wave-level count, one atomic per wave
@@ -138,7 +142,10 @@ __global__ void bpr_unsort_neg_kernel(const int32_t *__restrict__ slot_neg, cons
                                       int32_t *__restrict__ out, int64_t n) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; t < n; t += stride) out[slot_local[t]] = slot_neg[t];
+    for (; t < n; t += stride) {
+        const int32_t j = slot_neg[t];
+        out[slot_local[t]] = j < 0 ? j : (j & 0x3fffffff);
+    }
 }
 
 // ---------------------------------------------------------------- THROUGHPUT: the step kernel
@@ -159,7 +166,7 @@ __device__ __forceinline__ void atomic_add_row(float *__restrict__ dst, const Ro
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int k = RowT::kof(lane, r);
-        if (k < K) atomicAdd(dst + k, a.v[r] - b.v[r]);      // no-return global_atomic_add_f32
+        if (RowT::packed || k < K) atomicAdd(dst + k, a.v[r] - b.v[r]);      // no-return global_atomic_add_f32
     }
 }
 
@@ -169,13 +176,22 @@ __device__ __forceinline__ void exchange_row(float *__restrict__ dst, RowT &cur,
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int k = RowT::kof(lane, r);
-        if (k < K) {
+        if (RowT::packed || k < K) {
             const float dlt = cur.v[r] - base.v[r];
             const float found = atomicAdd(dst + k, dlt);    // returning form
             cur.v[r] = found + dlt;
             base.v[r] = cur.v[r];
         }
     }
+}
+
+// Pins the s_waitcnt of loads/atomic returns into the (rare) branch that issued them.  Without
+// it hipcc sinks the wait to the next use after the branch merge, i.e. a vmcnt(0) on the common
+// path that drains the whole prefetch ring at every triplet.
+template <typename RowT, int R>
+__device__ __forceinline__ void settle(RowT &a) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(a.v[r]));
 }
 
 template <int R, bool PACKED, int OPT, int PF>
@@ -188,98 +204,123 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     using RowT = Row<float, R, PACKED>;
     constexpr int NS = opt_num_states(OPT);
     constexpr int NSA = NS ? NS : 1;
+    static_assert(64 % PF == 0, "ring depth must divide the chunk");
+    const int diag = xcd_stride >> 8;      // developer diagnostics (tools/sweep_step.py): bit0 no H[j] atomics, bit1 no W store, bit2 all H[j] atomic
+    xcd_stride &= 255;
+    if (blockIdx.x % xcd_stride) return;   // diagnostic: xcd_stride 8 keeps every active block on one XCD
     const int lane = lane_id();
     const int K = d.K;
     const int64_t n_chunks = (slot_end - slot_begin + 63) >> 6;
-    if (blockIdx.x % xcd_stride) return;   // diagnostic: xcd_stride 8 keeps every active block on one XCD
     const int64_t wave = ((int64_t)(blockIdx.x / xcd_stride) * blockDim.x + threadIdx.x) >> 6;
     const int64_t c_begin = wave * chunks_per_wave;
     const int64_t c_end = c_begin + chunks_per_wave < n_chunks ? c_begin + chunks_per_wave : n_chunks;
+    if (c_begin >= c_end) return;
     float loss_sum = 0.0f;
     unsigned int n_done = 0;
+    float *const Ws[2] = {d.W0, d.W1};
     float *const Hs[2] = {d.H0, d.H1};
+
+    // slot metadata of the current and the next chunk, one slot per lane; j < 0 = nothing to do
+    // (skipped draw, or past the end of the step); such slots gather row 0 and are predicated off.
+    auto load_meta = [&](int64_t c, int32_t &u, int32_t &i, int32_t &j) {
+        const int64_t my = slot_begin + (c << 6) + lane;
+        const bool in = c < c_end && my < slot_end;
+        u = in ? slot_user[my] : 0;
+        i = in ? slot_item[my] : 0;
+        j = in ? slot_neg[my] : -1;
+        if (j < 0) u = 0;
+    };
+    int32_t u_c, i_c, j_c, u_n, i_n, j_n;
+    load_meta(c_begin, u_c, i_c, j_c);
+    load_meta(c_begin + 1, u_n, i_n, j_n);
+
+    // ring of PF gathered (W[u], H[j]) row pairs (+ optimizer state rows): entry p holds slot
+    // t with t % PF == p; it is refilled with slot t + PF right after slot t was consumed, so
+    // PF triplets' rows are always in flight, across chunk boundaries too.
+    RowT wq[PF], jq[PF], swq[PF][NSA], sjq[PF][NSA];
+    auto issue = [&](int p, int32_t u, int32_t j) {
+        const int64_t ou = (int64_t)u * K, oj = (int64_t)(j < 0 ? 0 : (j & 0x3fffffff)) * K;
+        wq[p].load(d.W + ou, K, lane);
+        jq[p].load(d.H + oj, K, lane);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { swq[p][q].load(Ws[q] + ou, K, lane); sjq[p][q].load(Hs[q] + oj, K, lane); }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) issue(p, bcast_lane(u_c, p), bcast_lane(j_c, p));
 
     int cur_item = -1;
     RowT hi, hi0, shi[NSA], shi0[NSA];
+    hi.fill(0.0f); hi0.fill(0.0f);
+#pragma unroll
+    for (int q = 0; q < NSA; ++q) { shi[q].fill(0.0f); shi0[q].fill(0.0f); }
 
     for (int64_t c = c_begin; c < c_end; ++c) {
-        const int64_t my = slot_begin + (c << 6) + lane;
-        const bool in = my < slot_end;
-        const int32_t u_l = in ? slot_user[my] : 0;
-        const int32_t i_l = in ? slot_item[my] : -1;
-        const int32_t j_l = in ? slot_neg[my] : -1;
-        unsigned long long pend = __ballot(j_l >= 0);     // performed slots whose rows are not yet requested
-        if (pend == 0) continue;
-        n_done += (unsigned int)__popcll(pend);
-
-        // ring of PF prefetched (W[u], H[j]) row pairs
-        RowT wq[PF], jq[PF], swq[PF][NSA], sjq[PF][NSA];
-        int uq[PF], jjq[PF], iq[PF];
-        int filled = 0;
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            uq[p] = jjq[p] = iq[p] = -1;
-            if (pend) {
-                const int t = __builtin_ctzll(pend);
-                pend &= pend - 1;
-                uq[p] = bcast_lane(u_l, t);
-                jjq[p] = bcast_lane(j_l, t);
-                iq[p] = bcast_lane(i_l, t);
-                wq[p].load(d.W + (int64_t)uq[p] * K, K, lane);
-                jq[p].load(d.H + (int64_t)jjq[p] * K, K, lane);
-                if constexpr (NS >= 1) { swq[p][0].load(d.W0 + (int64_t)uq[p] * K, K, lane); sjq[p][0].load(d.H0 + (int64_t)jjq[p] * K, K, lane); }
-                if constexpr (NS >= 2) { swq[p][1].load(d.W1 + (int64_t)uq[p] * K, K, lane); sjq[p][1].load(d.H1 + (int64_t)jjq[p] * K, K, lane); }
-                ++filled;
-            }
-        }
-        while (filled > 0) {
+        n_done += (unsigned int)__popcll(__ballot(j_c >= 0));
+        for (int t0 = 0; t0 < 64; t0 += PF) {
 #pragma unroll
             for (int p = 0; p < PF; ++p) {
-                if (uq[p] < 0) continue;   // wave-uniform
-                const int u = uq[p], j = jjq[p], item = iq[p];
-                if (item != cur_item) {
-                    if (cur_item >= 0) {   // the finished item run: H[i] += (hi - hi0)
-                        atomic_add_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
+                const int t = t0 + p;
+                const int u = bcast_lane(u_c, t), jraw = bcast_lane(j_c, t), item = bcast_lane(i_c, t);
+                const int j = jraw & 0x3fffffff;
+                const bool hot = (jraw >> 30) & 1;
+                if (jraw >= 0) {                               // wave-uniform
+                    if (item != cur_item) {                    // rare: next item run
+                        if (cur_item >= 0) {                   // H[i] += (hi - hi0) of the finished run
+                            atomic_add_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
 #pragma unroll
-                        for (int q = 0; q < NS; ++q) atomic_add_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+                            for (int q = 0; q < NS; ++q) atomic_add_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+                        }
+                        cur_item = item;
+                        hi.load(d.H + (int64_t)item * K, K, lane);
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) shi[q].load(Hs[q] + (int64_t)item * K, K, lane);
+                        settle<RowT, R>(hi);
+                        hi0 = hi;
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) { settle<RowT, R>(shi[q]); shi0[q] = shi[q]; }
                     }
-                    cur_item = item;
-                    hi.load(d.H + (int64_t)item * K, K, lane);
-                    hi0 = hi;
-                    if constexpr (NS >= 1) { shi[0].load(d.H0 + (int64_t)item * K, K, lane); shi0[0] = shi[0]; }
-                    if constexpr (NS >= 2) { shi[1].load(d.H1 + (int64_t)item * K, K, lane); shi0[1] = shi[1]; }
+                    RowT w = wq[p], hj = jq[p];
+                    RowT sw[NSA], shj[NSA];
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) { sw[q] = swq[p][q]; shj[q] = sjq[p][q]; }
+                    loss_sum += bpr_update_rows<float, R, PACKED, OPT>(d, w, hi, hj, sw, shi, shj);
+                    if (!(diag & 2)) w.store(d.W + (int64_t)u * K, K, lane);
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) sw[q].store(Ws[q] + (int64_t)u * K, K, lane);
+                    // H[j]: a cold negative is written back in place (HOGWILD); a hot one -- an item whose
+                    // positive-side deltas land every few microseconds -- gets its delta added atomically,
+                    // so that this write cannot undo them
+                    if (hot || (diag & 4)) {
+                        if (!(diag & 1)) atomic_add_row<RowT, R>(d.H + (int64_t)j * K, hj, jq[p], K, lane);
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) atomic_add_row<RowT, R>(Hs[q] + (int64_t)j * K, shj[q], sjq[p][q], K, lane);
+                    } else {
+                        hj.store(d.H + (int64_t)j * K, K, lane);
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) shj[q].store(Hs[q] + (int64_t)j * K, K, lane);
+                    }
                 }
-                RowT w = wq[p], hj = jq[p];
-                RowT sw[NSA], shj[NSA];
-                if constexpr (NS >= 1) { sw[0] = swq[p][0]; shj[0] = sjq[p][0]; }
-                if constexpr (NS >= 2) { sw[1] = swq[p][1]; shj[1] = sjq[p][1]; }
-                loss_sum += bpr_update_rows<float, R, PACKED, OPT>(d, w, hi, hj, sw, shi, shj);
-                w.store(d.W + (int64_t)u * K, K, lane);
-                atomic_add_row<RowT, R>(d.H + (int64_t)j * K, hj, jq[p], K, lane);
-                if constexpr (NS >= 1) { sw[0].store(d.W0 + (int64_t)u * K, K, lane); atomic_add_row<RowT, R>(d.H0 + (int64_t)j * K, shj[0], sjq[p][0], K, lane); }
-                if constexpr (NS >= 2) { sw[1].store(d.W1 + (int64_t)u * K, K, lane); atomic_add_row<RowT, R>(d.H1 + (int64_t)j * K, shj[1], sjq[p][1], K, lane); }
-                --filled;
-                uq[p] = -1;
-                if (pend) {   // refill this ring position
-                    const int t = __builtin_ctzll(pend);
-                    pend &= pend - 1;
-                    uq[p] = bcast_lane(u_l, t);
-                    jjq[p] = bcast_lane(j_l, t);
-                    iq[p] = bcast_lane(i_l, t);
-                    wq[p].load(d.W + (int64_t)uq[p] * K, K, lane);
-                    jq[p].load(d.H + (int64_t)jjq[p] * K, K, lane);
-                    if constexpr (NS >= 1) { swq[p][0].load(d.W0 + (int64_t)uq[p] * K, K, lane); sjq[p][0].load(d.H0 + (int64_t)jjq[p] * K, K, lane); }
-                    if constexpr (NS >= 2) { swq[p][1].load(d.W1 + (int64_t)uq[p] * K, K, lane); sjq[p][1].load(d.H1 + (int64_t)jjq[p] * K, K, lane); }
-                    ++filled;
-                }
+                // refill entry p with slot t + PF (of this chunk or the next one)
+                const int tn = t + PF;
+                const int32_t nu = tn < 64 ? bcast_lane(u_c, tn & 63) : bcast_lane(u_n, tn & 63);
+                const int32_t nj = tn < 64 ? bcast_lane(j_c, tn & 63) : bcast_lane(j_n, tn & 63);
+                issue(p, nu, nj);
             }
         }
         // chunk boundary: exchange the open item's progress with the other waves that share it
         if (cur_item >= 0 && c + 1 < c_end) {
             exchange_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
+            settle<RowT, R>(hi);
+            settle<RowT, R>(hi0);
 #pragma unroll
-            for (int q = 0; q < NS; ++q) exchange_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+            for (int q = 0; q < NS; ++q) {
+                exchange_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+                settle<RowT, R>(shi[q]);
+                settle<RowT, R>(shi0[q]);
+            }
         }
+        u_c = u_n; i_c = i_n; j_c = j_n;
+        load_meta(c + 2, u_n, i_n, j_n);
     }
     if (cur_item >= 0) {
         atomic_add_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
@@ -442,9 +483,13 @@ struct cymf_bpr {
     int32_t rows_per_inflight = 8;        // staleness bound: table rows per row in flight
     int32_t xcd_stride = 1;               // diagnostic (CYMF_BPR_XCD_STRIDE=8: all active blocks on one XCD)
     std::vector<int64_t> step_off;           // slot offsets, steps_per_epoch+1
-    DevBuf<int32_t> d_slot_user, d_slot_item, d_slot_neg;
+    DevBuf<int32_t> d_slot_user, d_slot_item, d_slot_neg[2];   // slot_neg double-buffered by epoch parity
+    hipEvent_t ev_epoch_done[2] = {nullptr, nullptr};          // last step of an epoch finished reading slot_neg[b]
+    int64_t epochs_sampled = 0;                                // throughput: epochs [0, epochs_sampled) have been sampled
     DevBuf<uint32_t> d_slot_pos, d_slot_local;
     DevBuf<unsigned long long> d_skipped, d_performed;
+    DevBuf<uint32_t> d_hot_bits;         // bit i set: item i is hot (see bpr_sample_kernel)
+    int32_t hot_threshold = 256;         // positives per step from which an item counts as hot
     int64_t slots_done = 0;              // slots walked by the step kernels since create
     DevBuf<int32_t> d_unsorted_neg;
 
@@ -506,7 +551,7 @@ constexpr int STEP_PF = 8;
 template <int R, bool PACKED>
 void launch_step_opt(int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn,
                      int64_t b, int64_t e, int64_t cpw, int xs, double *loss, unsigned long long *perf, int grid_blocks, hipStream_t s) {
-    dim3 grid(grid_blocks * xs), block(256);
+    dim3 grid(grid_blocks * (xs & 255)), block(256);
     switch (opt) {
     case CYMF_OPT_SGD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_SGD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, loss, perf); break;
     case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, loss, perf); break;
@@ -621,22 +666,36 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
 }
 
 // =============================== THROUGHPUT steps ===============================
+// Negatives of epoch e: generate (rng.hip) and resolve against the users' positives, both on the
+// rng stream, into the buffers of parity e & 1 -- one epoch ahead of the step kernels, so that the
+// whole sampling pipeline of epoch e+1 runs concurrently with the steps of epoch e.
+int prepare_epoch(cymf_bpr *h, int64_t e) {
+    while (h->epochs_sampled <= e) {
+        const int64_t g = h->epochs_sampled;
+        const int b = (int)(g & 1);
+        CYMF_TRY(request_epoch_draws(h, g));
+        // slot_neg[b] was last read by the steps of epoch g-2
+        if (g >= 2) CYMF_HIP(hipStreamWaitEvent(h->rng_stream, h->ev_epoch_done[b], 0));
+        if (h->N > 0) {
+            int blocks = (int)std::min<int64_t>((h->N + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(bpr_sample_kernel, dim3(blocks), dim3(256), 0, h->rng_stream, h->d_slot_user.p, h->d_slot_pos.p,
+                               h->d_draws[b].p, h->d_indptr.p, h->d_indices.p, h->d_hot_bits.p, h->d_slot_neg[b].p, h->N,
+                               h->d_skipped.p);
+            CYMF_HIP(hipGetLastError());
+        }
+        CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->rng_stream));
+        h->epochs_sampled++;
+    }
+    return 0;
+}
+
 int ensure_epoch_sampled(cymf_bpr *h) {
     if (h->epoch_sampled) return 0;
     const int64_t e = h->epoch_cursor;
-    const int b = (int)(e & 1);
-    CYMF_TRY(request_epoch_draws(h, e));
-    CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_gen[b], 0));
-    if (h->N > 0) {
-        int blocks = (int)std::min<int64_t>((h->N + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(bpr_sample_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_slot_user.p, h->d_slot_pos.p,
-                           h->d_draws[b].p, h->d_indptr.p, h->d_indices.p, h->d_slot_neg.p, h->N, h->d_skipped.p);
-        CYMF_HIP(hipGetLastError());
-    }
-    CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->stream));
+    CYMF_TRY(prepare_epoch(h, e));
+    CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_sampled[(int)(e & 1)], 0));
     h->epoch_sampled = true;
-    // run the generator one epoch ahead, concurrently with this epoch's steps
-    CYMF_TRY(request_epoch_draws(h, e + 1));
+    CYMF_TRY(prepare_epoch(h, e + 1));   // next epoch's negatives, concurrently with this epoch's steps
     return 0;
 }
 
@@ -666,7 +725,7 @@ int run_one_step(cymf_bpr *h) {
             }
             CYMF_HIP(hipEventRecord(p0, h->stream));
         }
-        launch_step(h->K, h->opt, d, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg.p, b, e, cpw, h->xcd_stride, h->d_loss.p, h->d_performed.p, grid, h->stream);
+        launch_step(h->K, h->opt, d, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, cpw, h->xcd_stride, h->d_loss.p, h->d_performed.p, grid, h->stream);
         CYMF_HIP(hipGetLastError());
         if (h->profiling) {
             CYMF_HIP(hipEventRecord(p1, h->stream));
@@ -686,6 +745,7 @@ int run_one_step(cymf_bpr *h) {
     }
     h->step_cursor++;
     if (h->step_cursor >= h->steps_per_epoch) {
+        CYMF_HIP(hipEventRecord(h->ev_epoch_done[(int)(h->epoch_cursor & 1)], h->stream));
         h->step_cursor = 0;
         h->epoch_cursor++;
         h->epoch_sampled = false;
@@ -712,6 +772,16 @@ int build_throughput_layout(cymf_bpr *h) {
     std::vector<int64_t> cnt((size_t)h->I + 1, 0);
     for (int64_t l = 0; l < N; ++l) cnt[(size_t)h->h_pos_items[l] + 1]++;
     for (int32_t i = 0; i < h->I; ++i) cnt[i + 1] += cnt[i];
+    {   // hot items: at least hot_threshold positives per step (cnt[] holds the bucket ends here)
+        std::vector<uint32_t> bits(((size_t)h->I + 31) / 32, 0u);
+        int64_t prev = 0;
+        for (int32_t i = 0; i < h->I; ++i) {
+            const int64_t n_i = cnt[i + 1] - prev;
+            prev = cnt[i + 1];
+            if (n_i >= (int64_t)h->hot_threshold * S) bits[i >> 5] |= 1u << (i & 31);
+        }
+        CYMF_TRY(h->d_hot_bits.upload(bits.data(), bits.size(), h->stream));
+    }
     std::vector<uint32_t> by_item((size_t)N);
     for (int64_t l = 0; l < N; ++l) by_item[(size_t)cnt[h->h_pos_items[l]]++] = (uint32_t)l;
     h->step_off.assign((size_t)S + 1, 0);
@@ -729,7 +799,8 @@ int build_throughput_layout(cymf_bpr *h) {
     CYMF_TRY(h->d_slot_item.upload(si.data(), si.size(), h->stream));
     CYMF_TRY(h->d_slot_pos.upload(sp.data(), sp.size(), h->stream));
     CYMF_TRY(h->d_slot_local.upload(sl.data(), sl.size(), h->stream));
-    CYMF_TRY(h->d_slot_neg.alloc((size_t)N));
+    CYMF_TRY(h->d_slot_neg[0].alloc((size_t)N));
+    CYMF_TRY(h->d_slot_neg[1].alloc((size_t)N));
     CYMF_TRY(h->d_skipped.alloc(1));
     CYMF_TRY(h->d_skipped.zero(h->stream));
     CYMF_TRY(h->d_performed.alloc(1));
@@ -776,6 +847,7 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
         e = hipEventCreateWithFlags(&h->ev_gen[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_epoch_done[b], hipEventDisableTiming);
     }
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
     int rc = h->d_loss.alloc(1);
@@ -789,6 +861,8 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
         h->f32.W.fine = h->f32.H.fine = h->f32.W0.fine = h->f32.W1.fine = h->f32.H0.fine = h->f32.H1.fine = f;
     }
     if (const char *e3 = getenv("CYMF_BPR_XCD_STRIDE")) h->xcd_stride = std::max(1, atoi(e3));
+    if (const char *e4 = getenv("CYMF_BPR_DIAG")) h->xcd_stride |= atoi(e4) << 8;
+    if (const char *e5 = getenv("CYMF_BPR_HOT_THRESHOLD")) h->hot_threshold = std::max(1, atoi(e5));
     if (const char *e1 = getenv("CYMF_BPR_MAX_WAVES")) h->max_waves = std::max(1, atoi(e1));
     if (const char *e2 = getenv("CYMF_BPR_ROWS_PER_INFLIGHT")) h->rows_per_inflight = std::max(1, atoi(e2));
     *out = h;
@@ -970,7 +1044,8 @@ extern "C" int cymf_bpr_last_negatives(cymf_bpr *h, int32_t *out, int64_t n) {
     }
     if (n == 0) return 0;
     CYMF_TRY(h->d_unsorted_neg.alloc((size_t)n));
-    hipLaunchKernelGGL(bpr_unsort_neg_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->d_slot_neg.p, h->d_slot_local.p,
+    hipLaunchKernelGGL(bpr_unsort_neg_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream,
+                       h->d_slot_neg[(int)((h->epoch_cursor - (h->step_cursor == 0 ? 1 : 0)) & 1)].p, h->d_slot_local.p,
                        h->d_unsorted_neg.p, n);
     CYMF_HIP(hipGetLastError());
     CYMF_HIP(hipMemcpyAsync(out, h->d_unsorted_neg.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -997,6 +1072,7 @@ extern "C" int cymf_bpr_destroy(cymf_bpr *h) {
     for (int b = 0; b < 2; ++b) {
         if (h->ev_gen[b]) (void)hipEventDestroy(h->ev_gen[b]);
         if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
+        if (h->ev_epoch_done[b]) (void)hipEventDestroy(h->ev_epoch_done[b]);
     }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->rng_stream) (void)hipStreamDestroy(h->rng_stream);

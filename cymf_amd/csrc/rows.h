@@ -15,6 +15,7 @@ namespace cymf {
 template <typename T, int R, bool PACKED>
 struct Row {
     T v[R];
+    static constexpr bool packed = PACKED;
 
     struct alignas(sizeof(T) * R) Vec { T x[R]; };
 
