@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output directories (gpurun_out/prof*/...) into profiles/:
+  python tools/summarize_prof.py <stats_dir> <fetch_dir> <write_dir> <tag>
+writes profiles/<tag>_summary.md and updates profiles/traffic.json (HBM bytes per launch of the
+dominant kernel: FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM' (gfx950 tallies 128-B read
+requests at 64 B), WRITE_SIZE as read; both counters are in KiB)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+stats_dir, fetch_dir, write_dir, tag = sys.argv[1:5]
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def kname(s):
+    m = re.search(r"(\w+_kernel|__amd\w+)", s)
+    return m.group(1) if m else s[:40]
+
+
+def counters(d, name):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == name:
+            agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+
+lines = [f"# rocprofv3 summary {tag}", "", "## --kernel-trace --stats (python3 bench.py --cpu-sample 0 --steps 50 --warmup 5)", "",
+         "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+f = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    lines.append(f'| {kname(r["Name"])} | {r["Calls"]} | {float(r["TotalDurationNs"])/1e6:.3f} | {float(r["AverageNs"])/1e3:.2f} | {float(r["Percentage"]):.2f} |')
+fetch, nf = counters(fetch_dir, "FETCH_SIZE")
+write, nw = counters(write_dir, "WRITE_SIZE")
+lines += ["", "## --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB per dispatch, mean)", "",
+          "| kernel | dispatches | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes/launch = (2*FETCH + WRITE)*1024 |", "|---|---|---|---|---|"]
+for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0))):
+    tot = (2 * fetch.get(k, 0) + write.get(k, 0)) * 1024
+    lines.append(f"| {k} | {nf.get(k, 0)} | {fetch.get(k, 0):.1f} | {write.get(k, 0):.1f} | {tot:.4g} |")
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+tpath = os.path.join(ROOT, "profiles", "traffic.json")
+traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+k = "bpr_step_kernel"
+traffic["bpr_step_sgd_K128"] = (2 * fetch[k] + write[k]) * 1024
+traffic["_source"] = f"profiles/{tag}_summary.md (C3, 4M triplets per launch)"
+json.dump(traffic, open(tpath, "w"), indent=1)
+print("\n".join(lines))
