@@ -54,10 +54,8 @@ class BPR(object):
 
         global_pos, n_global = None, len(users)
         if shard is not None:   # user-sharded: keep this rank's users, remember global positions
-            lo, hi = shard
-            keep = np.nonzero((users >= lo) & (users < hi))[0]
-            global_pos = keep.astype(np.int64)
-            users, positives = users[keep], positives[keep]
+            from .dist import shard_triplets
+            users, positives, global_pos = shard_triplets(users, positives, shard)
 
         trainer = BprTrainer(U, I, self.num_components, self.optimizer, self.learning_rate, self.weight_decay,
                              dtype=dtype, mode=mode, device=device, steps_per_epoch=steps_per_epoch, comm=comm)

@@ -30,6 +30,20 @@ def user_shards(indptr, world):
     return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
 
 
+def shard_triplets(users, positives, shard):
+    """This rank's triplets of the global shuffled order (its users only) and their positions in
+    that order, so that triplet l of epoch e consumes draw e*N_global + l on whichever rank holds it."""
+    lo, hi = shard
+    users = np.asarray(users)
+    keep = np.nonzero((users >= lo) & (users < hi))[0]
+    return users[keep], np.asarray(positives)[keep], keep.astype(np.int64)
+
+
+def step_of(global_pos, steps_per_epoch, n_global):
+    """Step (window of the global order) a triplet belongs to; mirrors build_throughput_layout in csrc/bpr.hip."""
+    return (np.asarray(global_pos, dtype=np.int64) * int(steps_per_epoch)) // max(int(n_global), 1)
+
+
 class Comm:
     """RCCL communicator handle (cymf_comm_*)."""
 

@@ -1,0 +1,74 @@
+"""Multi-GPU plumbing on the one GPU a test box has: the RCCL communicator at world size 1 (init,
+all-reduce, the per-step delta exchange of the trainer) and a user shard that consumes its own draws
+of the ONE global index stream.  World size > 1 is covered on CPU by tests/test_dist_gloo.py."""
+import numpy as np
+import pytest
+
+import oracle
+from cymf_amd import dist, synthetic
+from cymf_amd.bpr import BprTrainer
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(X, seed=5):
+    rs = np.random.RandomState(seed)
+    r, c = X.nonzero()
+    p = rs.permutation(len(r))
+    return r[p].astype(np.int32), c[p].astype(np.int32), X.indptr.astype(np.int32), X.indices.astype(np.int32)
+
+
+def test_rccl_world1_allreduce_and_trainer_exchange():
+    comm = dist.Comm(0, 1, 0, dist.Comm.unique_id())
+    a = np.arange(1000, dtype=np.float32)
+    assert np.array_equal(comm.allreduce(a), a) and np.array_equal(comm.allreduce(a, op="max"), a)
+    comm.barrier()
+    X = synthetic.implicit_matrix(4000, 3000, 200000, 61)
+    users, pos, indptr, indices = _inputs(X)
+    W0, H0 = oracle.reference_init(4000, 3000, 64)
+    out = []
+    for c in (None, comm):
+        t = BprTrainer(4000, 3000, 64, "sgd", 0.05, 0.01, mode="throughput", steps_per_epoch=5, comm=c)
+        t.set_data(users, pos, indptr, indices)
+        t.upload(W0, H0)
+        losses = t.epochs(3)
+        W, H = np.empty_like(W0), np.empty_like(H0)
+        t.download(W, H)
+        out.append((losses, W, H, t.stats()))
+        t.close()
+    # H = snapshot + allreduce(H - snapshot) after every step: same training up to HOGWILD noise
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-2)
+    assert out[0][3] == out[1][3]
+    assert abs(np.linalg.norm(out[0][2]) / np.linalg.norm(out[1][2]) - 1) < 1e-2
+    with pytest.raises(Exception):
+        BprTrainer(10, 10, 8, "adam", mode="throughput", comm=comm)     # sgd only in round 1
+    comm.close()
+
+
+def test_user_shard_consumes_its_draws_of_the_global_stream():
+    X = synthetic.implicit_matrix(3000, 2000, 120000, 62)
+    users, pos, indptr, indices = _inputs(X)
+    N, (U, I) = len(users), X.shape
+    shards = dist.user_shards(X.indptr, 3)
+    W0, H0 = oracle.reference_init(U, I, 16)
+    seen = np.zeros(N, dtype=np.int64)
+    for shard in shards:
+        u_l, p_l, gpos = dist.shard_triplets(users, pos, shard)
+        t = BprTrainer(U, I, 16, "sgd", 0.05, 0.01, mode="throughput", steps_per_epoch=4)
+        t.set_data(u_l, p_l, indptr, indices, global_pos=gpos, n_global=N)
+        t.upload(W0, H0)
+        for ep in range(2):
+            t.epochs(1)
+            draws = oracle.uniform_stream(1234, I, N, skip=ep * N).astype(np.int32)[gpos]
+            hit = np.asarray(X[u_l, draws]).ravel() != 0
+            assert np.array_equal(t.last_negatives(), np.where(hit, -1, draws))
+        seen[gpos] += 1
+        W = np.empty_like(W0)
+        H = np.empty_like(H0)
+        t.download(W, H)
+        lo, hi = shard
+        other = np.ones(U, dtype=bool)
+        other[lo:hi] = False
+        assert np.array_equal(W[other], W0[other].astype(np.float32).astype(np.float64))   # foreign user rows untouched
+        t.close()
+    assert (seen == 1).all()
