@@ -595,14 +595,22 @@ void launch_step_opt(int opt, const BprDev<float> &d, const int32_t *su, const i
     }
 }
 
+template <int R, bool PACKED>
+void launch_step_pf(int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn, int64_t b,
+                    int64_t e, int64_t cpw, int xs, double *loss, unsigned long long *perf, int grid_blocks, int pf,
+                    hipStream_t s) {
+    if constexpr (R >= 3) {   // K > 128: 4 rows ahead is what fits the register file without spilling
+        launch_step_opt<R, PACKED, 4>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s);
+    } else {
+        if (pf >= 16) launch_step_opt<R, PACKED, 16>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s);
+        else launch_step_opt<R, PACKED, 8>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s);
+    }
+}
+
 void launch_step(int K, int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn,
                  int64_t b, int64_t e, int64_t cpw, int xs, double *loss, unsigned long long *perf, int grid_blocks, int pf,
                  hipStream_t s) {
-#define CALL_(R_, P_)                                                                                  \
-    do {                                                                                               \
-        if (pf >= 16) launch_step_opt<R_, P_, 16>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s); \
-        else launch_step_opt<R_, P_, 8>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s);           \
-    } while (0)
+#define CALL_(R_, P_) launch_step_pf<R_, P_>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, pf, s)
     CYMF_DISPATCH_LAYOUT(K, CALL_);
 #undef CALL_
 }
@@ -751,7 +759,7 @@ int run_one_step(cymf_bpr *h) {
         // the hardware side, and few enough that the rows in flight (waves * PF) stay a small
         // fraction of the smaller table, so that two waves rarely hold the same row at once.
         int64_t waves = std::min<int64_t>(chunks, h->max_waves);
-        const int64_t by_rows = std::max<int64_t>(1, std::min(h->U, h->I) / ((int64_t)h->rows_per_inflight * h->step_pf));
+        const int64_t by_rows = std::max<int64_t>(1, std::min(h->U, h->I) / ((int64_t)h->rows_per_inflight * (h->K > 128 ? 4 : h->step_pf)));
         waves = std::max<int64_t>(1, std::min(waves, by_rows));
         const int64_t cpw = (chunks + waves - 1) / waves;
         waves = (chunks + cpw - 1) / cpw;

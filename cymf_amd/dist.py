@@ -66,7 +66,9 @@ class Comm:
         device = local if device is None else device
         port = os.environ.get("MASTER_PORT", "0")
         run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-        path = f"/tmp/cymf_amd_rdzv_{port}_{run}_{world}"
+        # the launcher (torchrun agent) is the common parent of all ranks: its pid makes the name
+        # unique per launch, so a file left behind by a crashed earlier run is never picked up
+        path = f"/tmp/cymf_amd_rdzv_{port}_{run}_{world}_{os.getppid()}"
         if rank == 0:
             uid = cls.unique_id()
             tmp = path + f".{os.getpid()}"
@@ -77,9 +79,7 @@ class Comm:
             t0 = time.time()
             while True:
                 try:
-                    # only accept a file written after this process started looking (stale files of an
-                    # earlier run with the same port are replaced by rank 0 first)
-                    if os.path.exists(path) and os.path.getmtime(path) >= _START - 120:
+                    if os.path.exists(path):
                         with open(path, "rb") as f:
                             uid = f.read()
                         if len(uid) == _lib.UNIQUE_ID_BYTES:
