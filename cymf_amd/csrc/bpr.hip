@@ -44,7 +44,7 @@ __device__ __forceinline__ double inv1pexp(double x) { return 1.0 / (1.0 + exp(x
 
 // forward (model.pyx:47-62) + backward (model.pyx:66-87) on rows already in registers.
 // Gradients of every component use the pre-update values (model.pyx:81-87).
-template <typename T, int R, bool PACKED, int OPT>
+template <typename T, int R, bool PACKED, int OPT, bool HOG = false>
 __device__ __forceinline__ T bpr_update_rows(const BprDev<T> &d, Row<T, R, PACKED> &w, Row<T, R, PACKED> &hi,
                                              Row<T, R, PACKED> &hj, Row<T, R, PACKED> *sw, Row<T, R, PACKED> *shi,
                                              Row<T, R, PACKED> *shj) {
@@ -65,9 +65,9 @@ __device__ __forceinline__ T bpr_update_rows(const BprDev<T> &d, Row<T, R, PACKE
         const T gi = -(s * wv - d.wd * iv);
         const T gj = -(s * (-wv) - d.wd * jv);
         T dummy = 0;
-        opt_update<T, OPT>(d.opt, w.v[r], OPT >= 1 ? sw[0].v[r] : dummy, OPT == 2 ? sw[1].v[r] : dummy, gw);
-        opt_update<T, OPT>(d.opt, hi.v[r], OPT >= 1 ? shi[0].v[r] : dummy, OPT == 2 ? shi[1].v[r] : dummy, gi);
-        opt_update<T, OPT>(d.opt, hj.v[r], OPT >= 1 ? shj[0].v[r] : dummy, OPT == 2 ? shj[1].v[r] : dummy, gj);
+        opt_update<T, OPT, HOG>(d.opt, w.v[r], OPT >= 1 ? sw[0].v[r] : dummy, OPT == 2 ? sw[1].v[r] : dummy, gw);
+        opt_update<T, OPT, HOG>(d.opt, hi.v[r], OPT >= 1 ? shi[0].v[r] : dummy, OPT == 2 ? shi[1].v[r] : dummy, gi);
+        opt_update<T, OPT, HOG>(d.opt, hj.v[r], OPT >= 1 ? shj[0].v[r] : dummy, OPT == 2 ? shj[1].v[r] : dummy, gj);
     }
     return loss;
 }
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
                                                       const int32_t *__restrict__ slot_item,
                                                       const int32_t *__restrict__ slot_neg, int64_t slot_begin,
                                                       int64_t slot_end, int64_t chunks_per_wave, int xcd_stride,
+                                                      const int64_t *__restrict__ wave_ranges, int64_t n_waves,
                                                       double *__restrict__ loss_acc,
                                                       unsigned long long *__restrict__ performed_acc) {
     using RowT = Row<float, R, PACKED>;
@@ -243,11 +244,24 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     if (blockIdx.x % xcd_stride) return;   // diagnostic: xcd_stride 8 keeps every active block on one XCD
     const int lane = lane_id();
     const int K = d.K;
-    const int64_t n_chunks = (slot_end - slot_begin + 63) >> 6;
     const int64_t wave = ((int64_t)(blockIdx.x / xcd_stride) * blockDim.x + threadIdx.x) >> 6;
-    const int64_t c_begin = wave * chunks_per_wave;
-    const int64_t c_end = c_begin + chunks_per_wave < n_chunks ? c_begin + chunks_per_wave : n_chunks;
-    if (c_begin >= c_end) return;
+    // this wave's slots [slot_begin, slot_end): either an equal share of the step (SGD: an item run may be
+    // split between waves, which then exchange at chunk boundaries) or an explicit ITEM-ALIGNED range
+    // (AdaGrad/Adam: a run belongs to one wave, see the host side)
+    const bool shared_runs = wave_ranges == nullptr;
+    if (wave >= n_waves) return;
+    if (shared_runs) {
+        const int64_t b0 = slot_begin + wave * chunks_per_wave * 64;
+        const int64_t e0 = b0 + chunks_per_wave * 64;
+        slot_begin = b0;
+        slot_end = e0 < slot_end ? e0 : slot_end;
+    } else {
+        slot_begin = wave_ranges[wave];
+        slot_end = wave_ranges[wave + 1];
+    }
+    const int64_t c_begin = 0;
+    const int64_t c_end = (slot_end - slot_begin + 63) >> 6;
+    if (c_end <= 0) return;
     float loss_sum = 0.0f;
     unsigned int n_done = 0;
     float *const Ws[2] = {d.W0, d.W1};
@@ -267,10 +281,15 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     load_meta(c_begin, u_c, i_c, j_c);
     load_meta(c_begin + 1, u_n, i_n, j_n);
 
-    // ring of PF gathered (W[u], H[j]) row pairs (+ optimizer state rows): entry p holds slot
-    // t with t % PF == p; it is refilled with slot t + PF right after slot t was consumed, so
-    // PF triplets' rows are always in flight, across chunk boundaries too.
-    RowT wq[PF], jq[PF], swq[PF][NSA], sjq[PF][NSA];
+    // Ring of RING = 2*PF entries of gathered (W[u], H[j]) row pairs (+ optimizer state rows): entry e
+    // holds slot t with t % RING == e.  Slot t is updated IN PLACE in its entry and stored from there;
+    // the entry refilled right after is (e + PF) % RING, whose stores were issued PF triplets ago.  So PF
+    // triplets' loads are in flight (across chunk boundaries too) and PF triplets' stores are draining,
+    // and no register that a pending store still reads is overwritten early -- hipcc guards such a
+    // reuse with s_waitcnt vmcnt(N) (N = operations issued since), which at N ~ 0 drains the ring.
+    constexpr int RING = 2 * PF;
+    static_assert(64 % RING == 0, "ring must divide the chunk");
+    RowT wq[RING], jq[RING], swq[RING][NSA], sjq[RING][NSA];
     auto issue = [&](int p, int32_t u, int32_t j) {
         const int64_t ou = (int64_t)u * K, oj = (int64_t)(j < 0 ? 0 : (j & 0x3fffffff)) * K;
         wq[p].load(d.W + ou, K, lane);
@@ -282,16 +301,17 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     for (int p = 0; p < PF; ++p) issue(p, bcast_lane(u_c, p), bcast_lane(j_c, p));
 
     int cur_item = -1;
-    RowT hi, hi0, shi[NSA], shi0[NSA];
+    RowT hi, hi0, shi[NSA];
     hi.fill(0.0f); hi0.fill(0.0f);
 #pragma unroll
-    for (int q = 0; q < NSA; ++q) { shi[q].fill(0.0f); shi0[q].fill(0.0f); }
+    for (int q = 0; q < NSA; ++q) shi[q].fill(0.0f);
 
     for (int64_t c = c_begin; c < c_end; ++c) {
         n_done += (unsigned int)__popcll(__ballot(j_c >= 0));
-        for (int t0 = 0; t0 < 64; t0 += PF) {
+#pragma unroll 1
+        for (int t0 = 0; t0 < 64; t0 += RING) {
 #pragma unroll
-            for (int p = 0; p < PF; ++p) {
+            for (int p = 0; p < RING; ++p) {
                 const int t = t0 + p;
                 const int u = bcast_lane(u_c, t), jraw = bcast_lane(j_c, t), item = bcast_lane(i_c, t);
                 const int j = jraw & 0x3fffffff;
@@ -300,8 +320,11 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
                     if (item != cur_item) {                    // rare: next item run
                         if (cur_item >= 0) {                   // H[i] += (hi - hi0) of the finished run
                             atomic_add_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
+                            // the run's optimizer state is written back as the consistent set this wave holds.
+                            // It is never delta-summed: a fast EMA (Adam's m decays ~completely within 64
+                            // updates) summed over c waves has gain -(c-1) per exchange and diverges for c >= 3.
 #pragma unroll
-                            for (int q = 0; q < NS; ++q) atomic_add_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+                            for (int q = 0; q < NS; ++q) shi[q].store(Hs[q] + (int64_t)cur_item * K, K, lane);
                         }
                         cur_item = item;
                         hi.load(d.H + (int64_t)item * K, K, lane);
@@ -310,47 +333,36 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
                         settle<RowT, R>(hi);
                         hi0 = hi;
 #pragma unroll
-                        for (int q = 0; q < NS; ++q) { settle<RowT, R>(shi[q]); shi0[q] = shi[q]; }
+                        for (int q = 0; q < NS; ++q) settle<RowT, R>(shi[q]);
                     }
-                    RowT w = wq[p], hj = jq[p];
-                    RowT sw[NSA], shj[NSA];
+                    const RowT hj_old = jq[p];
+                    loss_sum += bpr_update_rows<float, R, PACKED, OPT, true>(d, wq[p], hi, jq[p], swq[p], shi, sjq[p]);
+                    if (!(diag & 2)) wq[p].store(d.W + (int64_t)u * K, K, lane);
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) { sw[q] = swq[p][q]; shj[q] = sjq[p][q]; }
-                    loss_sum += bpr_update_rows<float, R, PACKED, OPT>(d, w, hi, hj, sw, shi, shj);
-                    if (!(diag & 2)) w.store(d.W + (int64_t)u * K, K, lane);
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) sw[q].store(Ws[q] + (int64_t)u * K, K, lane);
+                    for (int q = 0; q < NS; ++q) swq[p][q].store(Ws[q] + (int64_t)u * K, K, lane);
                     // H[j]: a cold negative is written back in place (HOGWILD); a hot one -- an item whose
                     // positive-side deltas land every few microseconds -- gets its delta added atomically,
                     // so that this write cannot undo them
                     if (hot || (diag & 4)) {
-                        if (!(diag & 1)) atomic_add_row<RowT, R>(d.H + (int64_t)j * K, hj, jq[p], K, lane);
-#pragma unroll
-                        for (int q = 0; q < NS; ++q) atomic_add_row<RowT, R>(Hs[q] + (int64_t)j * K, shj[q], sjq[p][q], K, lane);
+                        if (!(diag & 1)) atomic_add_row<RowT, R>(d.H + (int64_t)j * K, jq[p], hj_old, K, lane);
                     } else {
-                        hj.store(d.H + (int64_t)j * K, K, lane);
-#pragma unroll
-                        for (int q = 0; q < NS; ++q) shj[q].store(Hs[q] + (int64_t)j * K, K, lane);
+                        jq[p].store(d.H + (int64_t)j * K, K, lane);
                     }
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) sjq[p][q].store(Hs[q] + (int64_t)j * K, K, lane);
                 }
-                // refill entry p with slot t + PF (of this chunk or the next one)
+                // refill the entry PF ahead with slot t + PF (of this chunk or the next one)
                 const int tn = t + PF;
                 const int32_t nu = tn < 64 ? bcast_lane(u_c, tn & 63) : bcast_lane(u_n, tn & 63);
                 const int32_t nj = tn < 64 ? bcast_lane(j_c, tn & 63) : bcast_lane(j_n, tn & 63);
-                issue(p, nu, nj);
+                issue((p + PF) % RING, nu, nj);
             }
         }
         // chunk boundary: exchange the open item's progress with the other waves that share it
-        if (cur_item >= 0 && c + 1 < c_end) {
+        if (shared_runs && cur_item >= 0 && c + 1 < c_end) {
             exchange_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
             settle<RowT, R>(hi);
             settle<RowT, R>(hi0);
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                exchange_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
-                settle<RowT, R>(shi[q]);
-                settle<RowT, R>(shi0[q]);
-            }
         }
         u_c = u_n; i_c = i_n; j_c = j_n;
         load_meta(c + 2, u_n, i_n, j_n);
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     if (cur_item >= 0) {
         atomic_add_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) atomic_add_row<RowT, R>(Hs[q] + (int64_t)cur_item * K, shi[q], shi0[q], K, lane);
+        for (int q = 0; q < NS; ++q) shi[q].store(Hs[q] + (int64_t)cur_item * K, K, lane);
     }
     if (lane == 0 && n_done) {
         atomicAdd(loss_acc, (double)loss_sum);
@@ -516,6 +528,8 @@ struct cymf_bpr {
     int32_t steps_per_epoch = 1;
     int32_t max_waves = 256 * 8;          // hardware side: 8 wavefronts per CU
     int32_t rows_per_inflight = 8;        // staleness bound: table rows per row in flight
+    bool item_aligned = false;            // experiment: AdaGrad/Adam item runs owned by one wave (CYMF_BPR_ITEM_ALIGNED=1)
+    int32_t adaptive_rpi_factor = 2;      // AdaGrad/Adam: stricter rows-in-flight bound (state RMW is not atomic)
     int32_t step_pf = 8;                  // prefetch ring depth of the step kernel (8 or 16)
     int32_t xcd_stride = 1;               // diagnostic (CYMF_BPR_XCD_STRIDE=8: all active blocks on one XCD)
     std::vector<int64_t> step_off;           // slot offsets, steps_per_epoch+1
@@ -524,6 +538,10 @@ struct cymf_bpr {
     int64_t epochs_sampled = 0;                                // throughput: epochs [0, epochs_sampled) have been sampled
     DevBuf<uint32_t> d_slot_pos, d_slot_local;
     DevBuf<unsigned long long> d_skipped, d_performed;
+    DevBuf<int64_t> d_wave_ranges;       // AdaGrad/Adam: item-aligned slot ranges of the waves, all steps
+    std::vector<int64_t> wave_range_off; // per step: offset into d_wave_ranges (n_ranges + 1 entries each)
+    std::vector<int32_t> h_slot_item;    // host copy of slot_item (range construction)
+    int64_t wave_ranges_for = -1;
     DevBuf<uint32_t> d_hot_bits;         // bit i set: item i is hot (see bpr_sample_kernel)
     int32_t hot_threshold = 256;         // positives per step from which an item counts as hot
     int64_t slots_done = 0;              // slots walked by the step kernels since create
@@ -586,31 +604,33 @@ void launch_level(int K, int opt, const BprDev<T> &d, const int32_t *tu, const i
 
 template <int R, bool PACKED, int STEP_PF>
 void launch_step_opt(int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn,
-                     int64_t b, int64_t e, int64_t cpw, int xs, double *loss, unsigned long long *perf, int grid_blocks, hipStream_t s) {
+                     int64_t b, int64_t e, int64_t cpw, int xs, const int64_t *wr, int64_t nw, double *loss, unsigned long long *perf, int grid_blocks, hipStream_t s) {
     dim3 grid(grid_blocks * (xs & 255)), block(256);
     switch (opt) {
-    case CYMF_OPT_SGD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_SGD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, loss, perf); break;
-    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, loss, perf); break;
-    default: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAM, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, loss, perf); break;
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_SGD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
+    default: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAM, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
     }
 }
 
 template <int R, bool PACKED>
 void launch_step_pf(int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn, int64_t b,
-                    int64_t e, int64_t cpw, int xs, double *loss, unsigned long long *perf, int grid_blocks, int pf,
-                    hipStream_t s) {
-    if constexpr (R >= 3) {   // K > 128: 4 rows ahead is what fits the register file without spilling
-        launch_step_opt<R, PACKED, 4>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s);
+                    int64_t e, int64_t cpw, int xs, const int64_t *wr, int64_t nw, double *loss, unsigned long long *perf,
+                    int grid_blocks, int pf, hipStream_t s) {
+    if constexpr (R >= 3) {   // K > 128: 4 rows ahead (ring of 8) is what fits the register file without spilling
+        launch_step_opt<R, PACKED, 4>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
+    } else if (opt == CYMF_OPT_ADAM) {   // 6 rows per entry
+        launch_step_opt<R, PACKED, 4>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
     } else {
-        if (pf >= 16) launch_step_opt<R, PACKED, 16>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s);
-        else launch_step_opt<R, PACKED, 8>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, s);
+        (void)pf;
+        launch_step_opt<R, PACKED, 8>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
     }
 }
 
 void launch_step(int K, int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn,
-                 int64_t b, int64_t e, int64_t cpw, int xs, double *loss, unsigned long long *perf, int grid_blocks, int pf,
-                 hipStream_t s) {
-#define CALL_(R_, P_) launch_step_pf<R_, P_>(opt, d, su, si, sn, b, e, cpw, xs, loss, perf, grid_blocks, pf, s)
+                 int64_t b, int64_t e, int64_t cpw, int xs, const int64_t *wr, int64_t nw, double *loss, unsigned long long *perf,
+                 int grid_blocks, int pf, hipStream_t s) {
+#define CALL_(R_, P_) launch_step_pf<R_, P_>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, pf, s)
     CYMF_DISPATCH_LAYOUT(K, CALL_);
 #undef CALL_
 }
@@ -748,6 +768,36 @@ int ensure_epoch_sampled(cymf_bpr *h) {
     return 0;
 }
 
+// AdaGrad / Adam: an item run is owned by ONE wavefront (its optimizer state cannot be merged, see the
+// kernel).  Greedy cut of every step's item-sorted slots into ranges of about slots/waves, moved to
+// the next item boundary; a run longer than the target becomes a range of its own (the step's tail).
+int ensure_wave_ranges(cymf_bpr *h, int64_t waves_target) {
+    if (h->wave_ranges_for == waves_target && h->d_wave_ranges.p) return 0;
+    std::vector<int64_t> all;
+    h->wave_range_off.assign((size_t)h->steps_per_epoch + 1, 0);
+    for (int32_t s = 0; s < h->steps_per_epoch; ++s) {
+        const int64_t b = h->step_off[s], e = h->step_off[s + 1];
+        h->wave_range_off[s] = (int64_t)all.size();
+        const int64_t target = std::max<int64_t>(64, (e - b + waves_target - 1) / std::max<int64_t>(waves_target, 1));
+        int64_t start = b;
+        all.push_back(b);
+        while (start < e) {
+            int64_t cut = std::min(e, start + target);
+            if (cut < e) {   // advance to the end of the item run that contains slot cut-1
+                const int32_t item = h->h_slot_item[(size_t)cut - 1];
+                while (cut < e && h->h_slot_item[(size_t)cut] == item) ++cut;
+            }
+            all.push_back(cut);
+            start = cut;
+        }
+    }
+    h->wave_range_off[(size_t)h->steps_per_epoch] = (int64_t)all.size();
+    CYMF_TRY(h->d_wave_ranges.upload(all.data(), all.size(), h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
+    h->wave_ranges_for = waves_target;
+    return 0;
+}
+
 int run_one_step(cymf_bpr *h) {
     CYMF_TRY(ensure_epoch_sampled(h));
     const int32_t s = h->step_cursor;
@@ -759,10 +809,18 @@ int run_one_step(cymf_bpr *h) {
         // the hardware side, and few enough that the rows in flight (waves * PF) stay a small
         // fraction of the smaller table, so that two waves rarely hold the same row at once.
         int64_t waves = std::min<int64_t>(chunks, h->max_waves);
-        const int64_t by_rows = std::max<int64_t>(1, std::min(h->U, h->I) / ((int64_t)h->rows_per_inflight * (h->K > 128 ? 4 : h->step_pf)));
+        // adaptive optimizers carry per-row state whose read-modify-write is not atomic: 4x stricter
+        const int64_t rpi = (int64_t)h->rows_per_inflight * (h->opt == CYMF_OPT_SGD ? 1 : h->adaptive_rpi_factor);
+        const int64_t by_rows = std::max<int64_t>(1, std::min(h->U, h->I) / (rpi * (h->K > 128 || h->opt == CYMF_OPT_ADAM ? 4 : h->step_pf)));
         waves = std::max<int64_t>(1, std::min(waves, by_rows));
-        const int64_t cpw = (chunks + waves - 1) / waves;
+        int64_t cpw = (chunks + waves - 1) / waves;
         waves = (chunks + cpw - 1) / cpw;
+        const int64_t *wave_ranges = nullptr;
+        if (h->item_aligned && h->opt != CYMF_OPT_SGD) {   // item-aligned ranges (experiment: single-wave runs are tail-bound)
+            CYMF_TRY(ensure_wave_ranges(h, waves));
+            wave_ranges = h->d_wave_ranges.p + h->wave_range_off[s];
+            waves = h->wave_range_off[s + 1] - h->wave_range_off[s] - 1;
+        }
         const int grid = (int)((waves + 3) / 4);
         hipEvent_t p0 = nullptr, p1 = nullptr;
         if (h->profiling) {
@@ -774,7 +832,7 @@ int run_one_step(cymf_bpr *h) {
             }
             CYMF_HIP(hipEventRecord(p0, h->stream));
         }
-        launch_step(h->K, h->opt, d, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, cpw, h->xcd_stride, h->d_loss.p, h->d_performed.p, grid, h->step_pf, h->stream);
+        launch_step(h->K, h->opt, d, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, cpw, h->xcd_stride, wave_ranges, waves, h->d_loss.p, h->d_performed.p, grid, h->step_pf, h->stream);
         CYMF_HIP(hipGetLastError());
         if (h->profiling) {
             CYMF_HIP(hipEventRecord(p1, h->stream));
@@ -846,6 +904,8 @@ int build_throughput_layout(cymf_bpr *h) {
     }
     CYMF_TRY(h->d_slot_user.upload(su.data(), su.size(), h->stream));
     CYMF_TRY(h->d_slot_item.upload(si.data(), si.size(), h->stream));
+    if (h->item_aligned && h->opt != CYMF_OPT_SGD) h->h_slot_item = si;
+    h->wave_ranges_for = -1;
     CYMF_TRY(h->d_slot_pos.upload(sp.data(), sp.size(), h->stream));
     CYMF_TRY(h->d_slot_local.upload(sl.data(), sl.size(), h->stream));
     {   // membership table over the CSR pattern (device build, a few ms)
@@ -922,7 +982,8 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
     }
     if (const char *e3 = getenv("CYMF_BPR_XCD_STRIDE")) h->xcd_stride = std::max(1, atoi(e3));
     if (const char *e4 = getenv("CYMF_BPR_DIAG")) h->xcd_stride |= atoi(e4) << 8;
-    if (const char *e6 = getenv("CYMF_BPR_PF")) h->step_pf = atoi(e6) >= 16 ? 16 : 8;
+    if (const char *e7 = getenv("CYMF_BPR_ITEM_ALIGNED")) h->item_aligned = e7[0] == '1';
+    if (const char *e8 = getenv("CYMF_BPR_ADAPTIVE_RPI")) h->adaptive_rpi_factor = std::max(1, atoi(e8));
     if (const char *e5 = getenv("CYMF_BPR_HOT_THRESHOLD")) h->hot_threshold = std::max(1, atoi(e5));
     if (const char *e1 = getenv("CYMF_BPR_MAX_WAVES")) h->max_waves = std::max(1, atoi(e1));
     if (const char *e2 = getenv("CYMF_BPR_ROWS_PER_INFLIGHT")) h->rows_per_inflight = std::max(1, atoi(e2));

@@ -79,7 +79,11 @@ inline OptParams<T> make_opt_params(double lr) {
 __device__ __forceinline__ float fsqrt(float x) { return __fsqrt_rn(x); }
 __device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
 
-template <typename T, int OPT>
+// HOG = true (throughput kernels): several wavefronts may add their deltas of a shared row's Adam
+// moments, which can pair a (nearly) zeroed v with a live m; in sequential execution the two EMAs
+// always satisfy m^2 <= v (1-b1)^2 / ((1-b2)(1-b1^2/b2)) (Cauchy-Schwarz), so clamping v from below
+// with that bound is a no-op there and keeps the HOGWILD step bounded (|step| <= 2.3 lr).
+template <typename T, int OPT, bool HOG = false>
 __device__ __forceinline__ void opt_update(const OptParams<T> &o, T &p, T &s0, T &s1, T g) {
     if constexpr (OPT == CYMF_OPT_SGD) {
         p -= o.lr * g;
@@ -87,9 +91,15 @@ __device__ __forceinline__ void opt_update(const OptParams<T> &o, T &p, T &s0, T
         s0 += g * g;
         p -= o.lr * g / fsqrt(s0);
     } else {
+        if constexpr (HOG) s1 = s1 < T(0) ? T(0) : s1;
         s0 = o.b1 * s0 + o.omb1 * g;
         s1 = o.b2 * s1 + o.omb2 * (g * g);
-        p -= o.lr * (s0 / o.omb1) / (fsqrt(s1 / o.omb2) + o.eps);
+        T v = s1;
+        if constexpr (HOG) {
+            const T bound = s0 * s0 * (o.omb2 * (T(1) - o.b1 * o.b1 / o.b2) / (o.omb1 * o.omb1));
+            v = v < bound ? bound : v;
+        }
+        p -= o.lr * (s0 / o.omb1) / (fsqrt(v / o.omb2) + o.eps);
     }
 }
 

@@ -174,7 +174,7 @@ def test_throughput_mode_tracks_sequential_training(opt, lr, epochs):
     mt = BPR(K, lr, opt, 0.01)
     mt.fit(X, num_epochs=epochs, num_threads=8, verbose=False)
     W, H, losses = _oracle_in_bucketed_order(X, K, opt, lr, 0.01, epochs)
-    assert mt.losses[-1] < 0.75 * mt.losses[0]
+    assert mt.losses[-1] < 0.8 * mt.losses[0]
     np.testing.assert_allclose(mt.losses[-3:], losses[-3:], rtol=3e-2)
     assert abs(np.linalg.norm(mt.W) / np.linalg.norm(W) - 1) < 0.1
     assert abs(np.linalg.norm(mt.H) / np.linalg.norm(H) - 1) < 0.1
