@@ -23,7 +23,7 @@ OPT_IDS = {"sgd": 0, "adagrad": 1, "adam": 2}
 
 def build(force: bool = False) -> str:
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-std=c99", "-fPIC", "-shared",
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-std=c99", "-fPIC", "-shared",
                                "-Wall", _SRC, "-o", _SO, "-lm"])
     return _SO
 
@@ -47,6 +47,10 @@ def lib():
         L.orc_bpr_epoch.restype = f64
         L.orc_bpr_apply.argtypes = [vp, vp, vp, vp, i64]
         L.orc_bpr_apply.restype = f64
+        L.orc_bpr_epoch_hogwild.argtypes = [vp, vp, vp, i64, vp, vp, C.c_int, vp]
+        L.orc_bpr_epoch_hogwild.restype = f64
+        L.orc_max_threads.argtypes = []
+        L.orc_max_threads.restype = C.c_int
         L.orc_relmf_create.argtypes = [i32, i32, i32, C.c_int, f64, f64, f64, u32, vp, vp]
         L.orc_relmf_create.restype = vp
         L.orc_relmf_destroy.argtypes = [vp]
@@ -64,6 +68,10 @@ def lib():
             fn.restype = f64
         _lib = L
     return _lib
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
 
 
 def _p(a):
@@ -107,6 +115,15 @@ class Bpr:
         neg = np.empty(len(users), dtype=np.int32) if want_negatives else None
         loss = lib().orc_bpr_epoch(self.h, _p(users), _p(positives), len(users), _p(indptr), _p(indices), _p(neg))
         return (loss, neg) if want_negatives else loss
+
+    def epoch_hogwild(self, users, positives, indptr, indices, n_threads):
+        """All-thread lock-free epoch (cpu_baseline leg); returns (mean loss, performed)."""
+        users, positives = _c(users, np.int32), _c(positives, np.int32)
+        indptr, indices = _c(indptr, np.int32), _c(indices, np.int32)
+        done = C.c_int64(0)
+        loss = lib().orc_bpr_epoch_hogwild(self.h, _p(users), _p(positives), len(users), _p(indptr), _p(indices),
+                                           int(n_threads), C.byref(done))
+        return loss, done.value
 
     def apply(self, u, i, j):
         u, i, j = _c(u, np.int32), _c(i, np.int32), _c(j, np.int32)

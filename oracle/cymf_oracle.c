@@ -18,6 +18,9 @@
  * Every function cites the reference lines it restates (paths relative to /root/reference).
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -250,6 +253,40 @@ double orc_bpr_epoch(orc_bpr *m, const int32_t *users, const int32_t *positives,
         if (csr_has(indptr, indices, u, j)) { m->n_skipped++; continue; }
         accum += bpr_triplet(m, u, i, j);
     }
+    return N ? accum / (double)N : 0.0;
+}
+
+/* HOGWILD counterpart of orc_bpr_epoch for the cpu_baseline timing leg only: the reference's
+ * `prange(N, schedule="guided")` over lock-free shared W/H (bpr.pyx:162), with the epoch's draws taken
+ * from the stream up front (the reference shares one unlocked mt19937 between its threads, which is a
+ * data race; drawing first gives every triplet the draw of its position).  Nondeterministic by design. */
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+double orc_bpr_epoch_hogwild(orc_bpr *m, const int32_t *users, const int32_t *positives, int64_t N,
+                             const int32_t *indptr, const int32_t *indices, int n_threads, int64_t *performed_out)
+{
+    int32_t *neg = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    for (int64_t l = 0; l < N; ++l) neg[l] = (int32_t)orc_rng_next(&m->gen);
+    double accum = 0.0;
+    int64_t performed = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(guided) reduction(+ : accum, performed)
+#endif
+    for (int64_t l = 0; l < N; ++l) {
+        if (csr_has(indptr, indices, users[l], neg[l])) continue;
+        accum += bpr_triplet(m, users[l], positives[l], neg[l]);
+        performed++;
+    }
+    (void)n_threads;
+    free(neg);
+    if (performed_out) *performed_out = performed;
     return N ? accum / (double)N : 0.0;
 }
 
