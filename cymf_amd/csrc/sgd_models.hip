@@ -177,6 +177,222 @@ __global__ __launch_bounds__(256) void glove_kernel(GloveDev<T> d, const int32_t
     if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
 }
 
+// ================================================================== GloVe THROUGHPUT: central-bucketed step kernel
+// Same construction as bpr_step_kernel (bpr.hip), with the central word in the role of the positive item:
+//   * pairs sorted by central word; wavefront w walks its own contiguous range of 64-pair chunks;
+//   * the central word's row, its AdaGrad accumulator row and its {bias, bias accumulator} pair live
+//     in registers across the run; at a chunk boundary the wave exchanges them with the other waves of
+//     the same run through RETURNING float atomics of its deltas (AdaGrad accumulators are sums of g^2,
+//     so adding deltas is exact for them), at a word switch it adds the deltas and loads the next word;
+//   * context rows (parameter + accumulator) and bias pairs are gathered PF pairs ahead in a ring of
+//     2*PF entries, updated in place and written back; a HOT context word (bit 30 of the context index)
+//     gets atomic deltas instead, so concurrent waves cannot undo each other's updates on such rows.
+// Biases are kept interleaved {bias, accumulator} per word (one 8-byte access).
+struct GloveStepDev {
+    float *W, *H, *aW, *aH;
+    float2 *bW2, *bH2;
+    int K;
+    float lr, x_max, alpha;
+};
+
+template <typename RowT, int R>
+__device__ __forceinline__ void gl_settle(RowT &a) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(a.v[r]));
+}
+template <typename RowT, int R>
+__device__ __forceinline__ void gl_atomic_add_row(float *__restrict__ dst, const RowT &a, const RowT &b, int K, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = RowT::kof(lane, r);
+        if (RowT::packed || k < K) atomicAdd(dst + k, a.v[r] - b.v[r]);
+    }
+}
+template <typename RowT, int R>
+__device__ __forceinline__ void gl_exchange_row(float *__restrict__ dst, RowT &cur, RowT &base, int K, int lane) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = RowT::kof(lane, r);
+        if (RowT::packed || k < K) {
+            const float dlt = cur.v[r] - base.v[r];
+            const float found = atomicAdd(dst + k, dlt);
+            cur.v[r] = found + dlt;
+            base.v[r] = cur.v[r];
+        }
+    }
+}
+
+template <int R, bool PACKED, int PF>
+__global__ __launch_bounds__(256) void glove_step_kernel(GloveStepDev d, const int32_t *__restrict__ central,
+                                                        const int32_t *__restrict__ context,
+                                                        const float *__restrict__ counts, int64_t n,
+                                                        int64_t chunks_per_wave, double *__restrict__ loss_acc) {
+    using RowT = Row<float, R, PACKED>;
+    constexpr int RING = 2 * PF;
+    static_assert(64 % RING == 0, "ring must divide the chunk");
+    const int lane = lane_id();
+    const int K = d.K;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t s_begin = wave * chunks_per_wave * 64;
+    const int64_t s_end = s_begin + chunks_per_wave * 64 < n ? s_begin + chunks_per_wave * 64 : n;
+    if (s_begin >= s_end) return;
+    const int64_t c_end = (s_end - s_begin + 63) >> 6;
+
+    auto load_meta = [&](int64_t c, int32_t &ce, int32_t &cx, float &lg, float &fw) {
+        const int64_t my = s_begin + (c << 6) + lane;
+        const bool in = c < c_end && my < s_end;
+        ce = in ? central[my] : -1;
+        cx = in ? context[my] : 0;
+        const float cnt = in ? counts[my] : 1.0f;
+        lg = logf(cnt);                                           // model.pyx:177
+        const float f = powf(cnt / d.x_max, d.alpha);             // weight_func, model.pyx:34-35
+        fw = f < 1.0f ? f : 1.0f;
+    };
+    int32_t ce_c, cx_c, ce_n, cx_n;
+    float lg_c, fw_c, lg_n, fw_n;
+    load_meta(0, ce_c, cx_c, lg_c, fw_c);
+    load_meta(1, ce_n, cx_n, lg_n, fw_n);
+
+    RowT hq[RING], ahq[RING];
+    float2 bhq[RING];
+    auto issue = [&](int e, int32_t cx) {
+        const int64_t ox = (int64_t)(cx & 0x3fffffff) * K;
+        hq[e].load(d.H + ox, K, lane);
+        ahq[e].load(d.aH + ox, K, lane);
+        bhq[e] = d.bH2[cx & 0x3fffffff];                          // wave-uniform address
+    };
+#pragma unroll
+    for (int e = 0; e < PF; ++e) issue(e, bcast_lane(cx_c, e));
+
+    int cur = -1;
+    RowT w, w0, aw, aw0;
+    w.fill(0.0f); w0.fill(0.0f); aw.fill(0.0f); aw0.fill(0.0f);
+    float2 bw = make_float2(0.0f, 0.0f), bw0 = bw;
+    float loss_sum = 0.0f;
+
+    auto flush_central = [&]() {   // add this wave's deltas of the finished run
+        gl_atomic_add_row<RowT, R>(d.W + (int64_t)cur * K, w, w0, K, lane);
+        gl_atomic_add_row<RowT, R>(d.aW + (int64_t)cur * K, aw, aw0, K, lane);
+        if (lane == 0) {
+            atomicAdd(&d.bW2[cur].x, bw.x - bw0.x);
+            atomicAdd(&d.bW2[cur].y, bw.y - bw0.y);
+        }
+    };
+
+    for (int64_t c = 0; c < c_end; ++c) {
+#pragma unroll 1
+        for (int t0 = 0; t0 < 64; t0 += RING) {
+#pragma unroll
+            for (int e = 0; e < RING; ++e) {
+                const int t = t0 + e;
+                const int ce = bcast_lane(ce_c, t), cxraw = bcast_lane(cx_c, t);
+                const int cx = cxraw & 0x3fffffff;
+                const bool hot = (cxraw >> 30) & 1;
+                const float lg = __builtin_bit_cast(float, bcast_lane(__builtin_bit_cast(int, lg_c), t));
+                const float fw = __builtin_bit_cast(float, bcast_lane(__builtin_bit_cast(int, fw_c), t));
+                if (ce >= 0) {                                     // wave-uniform
+                    if (ce != cur) {                               // rare: next central word
+                        if (cur >= 0) flush_central();
+                        cur = ce;
+                        w.load(d.W + (int64_t)ce * K, K, lane);
+                        aw.load(d.aW + (int64_t)ce * K, K, lane);
+                        bw = d.bW2[ce];
+                        gl_settle<RowT, R>(w);
+                        gl_settle<RowT, R>(aw);
+                        asm volatile("" : "+v"(bw.x), "+v"(bw.y));
+                        w0 = w; aw0 = aw; bw0 = bw;
+                    }
+                    const RowT h_old = hq[e], ah_old = ahq[e];
+                    const float2 bh_old = bhq[e];
+                    float pd = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) pd += w.v[r] * hq[e].v[r];
+                    float diff = wave_sum(pd);                     // model.pyx:174-175
+                    diff += bw.x + bhq[e].x;                       // :176
+                    diff -= lg;                                    // :177
+                    const float tmp = diff;
+                    diff *= fw;                                    // :179
+                    loss_sum += 0.5f * diff * tmp;                 // :180
+                    const float g2 = diff * diff;
+                    float pbw = 0, pbh = 0;                        // K-fold bias update, closed form (see glove_kernel)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int k = RowT::kof(lane, r);
+                        if (k < K) {   // lanes past K hold zeros (also in the accumulators): keep 0/sqrt(0) out of w
+                            pbw += 1.0f / fsqrt(bw.y + (float)(k + 1) * g2);
+                            pbh += 1.0f / fsqrt(bhq[e].y + (float)(k + 1) * g2);
+                            const float wv = w.v[r], hv = hq[e].v[r];
+                            const float gw = diff * hv, gh = diff * wv;
+                            aw.v[r] += gw * gw;
+                            w.v[r] -= d.lr * gw / fsqrt(aw.v[r]);
+                            ahq[e].v[r] += gh * gh;
+                            hq[e].v[r] -= d.lr * gh / fsqrt(ahq[e].v[r]);
+                        }
+                    }
+                    const float sbw = wave_sum(pbw), sbh = wave_sum(pbh);
+                    bw.x -= d.lr * diff * sbw;
+                    bw.y += (float)K * g2;
+                    bhq[e].x -= d.lr * diff * sbh;
+                    bhq[e].y += (float)K * g2;
+                    if (hot) {
+                        gl_atomic_add_row<RowT, R>(d.H + (int64_t)cx * K, hq[e], h_old, K, lane);
+                        gl_atomic_add_row<RowT, R>(d.aH + (int64_t)cx * K, ahq[e], ah_old, K, lane);
+                        if (lane == 0) {
+                            atomicAdd(&d.bH2[cx].x, bhq[e].x - bh_old.x);
+                            atomicAdd(&d.bH2[cx].y, bhq[e].y - bh_old.y);
+                        }
+                    } else {
+                        hq[e].store(d.H + (int64_t)cx * K, K, lane);
+                        ahq[e].store(d.aH + (int64_t)cx * K, K, lane);
+                        if (lane == 0) d.bH2[cx] = bhq[e];
+                    }
+                }
+                const int tn = t + PF;
+                issue((e + PF) % RING, tn < 64 ? bcast_lane(cx_c, tn & 63) : bcast_lane(cx_n, tn & 63));
+            }
+        }
+        // chunk boundary: exchange the open central word's state with the waves that share its run
+        if (cur >= 0 && c + 1 < c_end) {
+            gl_exchange_row<RowT, R>(d.W + (int64_t)cur * K, w, w0, K, lane);
+            gl_exchange_row<RowT, R>(d.aW + (int64_t)cur * K, aw, aw0, K, lane);
+            float fx = 0.0f, fy = 0.0f;
+            if (lane == 0) {
+                fx = atomicAdd(&d.bW2[cur].x, bw.x - bw0.x);
+                fy = atomicAdd(&d.bW2[cur].y, bw.y - bw0.y);
+            }
+            fx = __builtin_bit_cast(float, bcast_lane(__builtin_bit_cast(int, fx), 0));
+            fy = __builtin_bit_cast(float, bcast_lane(__builtin_bit_cast(int, fy), 0));
+            bw.x = fx + (bw.x - bw0.x);
+            bw.y = fy + (bw.y - bw0.y);
+            bw0 = bw;
+            gl_settle<RowT, R>(w); gl_settle<RowT, R>(w0); gl_settle<RowT, R>(aw); gl_settle<RowT, R>(aw0);
+            asm volatile("" : "+v"(bw.x), "+v"(bw.y), "+v"(bw0.x), "+v"(bw0.y));
+        }
+        ce_c = ce_n; cx_c = cx_n; lg_c = lg_n; fw_c = fw_n;
+        load_meta(c + 2, ce_n, cx_n, lg_n, fw_n);
+    }
+    if (cur >= 0) flush_central();
+    if (lane == 0) atomicAdd(loss_acc, (double)loss_sum);
+}
+
+__global__ void pack2_kernel(const float *__restrict__ a, const float *__restrict__ b, float2 *__restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = make_float2(a[i], b[i]);
+}
+__global__ void unpack2_kernel(const float2 *__restrict__ in, float *__restrict__ a, float *__restrict__ b, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { a[i] = in[i].x; b[i] = in[i].y; }
+}
+
+void launch_glove_step(int K, const GloveStepDev &d, const int32_t *c, const int32_t *x, const float *cnt, int64_t n,
+                       int64_t cpw, double *loss, int grid, hipStream_t s) {
+#define CALL_(R_, P_) hipLaunchKernelGGL((glove_step_kernel<R_, P_, 8>), dim3(grid), dim3(256), 0, s, d, c, x, cnt, n, cpw, loss)
+    if (K <= 64) { CALL_(1, false); } else if (K == 128) { CALL_(2, true); } else { CALL_(2, false); }
+#undef CALL_
+}
+
 #define CYMF_DISPATCH_LAYOUT(K, CALL)                                                          \
     do {                                                                                       \
         const int R__ = ((K) + 63) / 64;                                                       \
@@ -390,6 +606,10 @@ struct GloveStore {
 };
 
 struct cymf_glove {
+    DevBuf<float2> bW2, bH2;        // throughput f32: {bias, accumulator} interleaved per word
+    DevBuf<float> d_counts_f32;     // throughput f32: counts in central-sorted order
+    bool step_path = false;         // throughput f32, K <= 128: central-bucketed step kernel
+    int64_t step_waves = 1;
     int32_t V = 0, Vc = 0, K = 0;
     int dtype = 0, mode = 0, device = 0;
     double lr = 0, x_max = 0, alpha = 0;
@@ -419,6 +639,8 @@ extern "C" int cymf_glove_create(cymf_glove **out, int32_t V, int32_t Vc, int32_
     if (mode == CYMF_MODE_THROUGHPUT) {   // rows are updated from all XCDs inside one kernel: see bpr.hip
         for (DevBuf<float> *b : {&h->f32.W, &h->f32.H, &h->f32.bW, &h->f32.bH, &h->f32.aW, &h->f32.aH, &h->f32.abW, &h->f32.abH}) b->fine = 2;
         for (DevBuf<double> *b : {&h->f64.W, &h->f64.H, &h->f64.bW, &h->f64.bH, &h->f64.aW, &h->f64.aH, &h->f64.abW, &h->f64.abH}) b->fine = 2;
+        h->bW2.fine = h->bH2.fine = 2;
+        h->step_path = dtype == CYMF_F32 && K <= 128 && V < (1 << 30) && !(getenv("CYMF_GLOVE_NO_STEP") && getenv("CYMF_GLOVE_NO_STEP")[0] == '1');
     }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -453,6 +675,24 @@ extern "C" int cymf_glove_set_data(cymf_glove *h, const int32_t *central, const 
         level_schedule(N, central, context, h->V, h->Vc, order, h->level_off);
         for (int64_t p = 0; p < N; ++p) { c[p] = central[order[p]]; x[p] = context[order[p]]; cnt[p] = counts[order[p]]; }
     }
+    if (h->step_path && N > 0) {
+        // central-bucketed order (stable) + hot context words: a word that is the context of at least
+        // HOT pairs is updated with atomic deltas by the step kernel; the number of wavefronts keeps the
+        // expected number of waves inside a COLD row's read-modify-write window at <= 2
+        std::vector<int64_t> nc((size_t)h->V + 1, 0), nx((size_t)h->Vc, 0);
+        for (int64_t s = 0; s < N; ++s) { nc[(size_t)central[s] + 1]++; nx[context[s]]++; }
+        for (int32_t v = 0; v < h->V; ++v) nc[v + 1] += nc[v];
+        const int64_t HOT = 4096;
+        std::vector<int64_t> cur(nc.begin(), nc.end() - 1);
+        for (int64_t s = 0; s < N; ++s) {
+            const int64_t p = cur[central[s]]++;
+            c[p] = central[s];
+            x[p] = context[s] | (nx[context[s]] >= HOT ? (1 << 30) : 0);
+            cnt[p] = counts[s];
+        }
+        const double f_cold = (double)std::min<int64_t>(HOT, N) / (double)N;
+        h->step_waves = std::max<int64_t>(1, std::min<int64_t>((int64_t)(2.0 / (f_cold * 8)), 256 * 8));
+    }
     CYMF_TRY(h->d_central.upload(c.data(), c.size(), h->stream));
     CYMF_TRY(h->d_context.upload(x.data(), x.size(), h->stream));
     if (h->dtype == CYMF_F32) CYMF_TRY(upload_f64(h->f32.counts, cnt.data(), cnt.size(), h->stream));
@@ -482,6 +722,14 @@ extern "C" int cymf_glove_upload(cymf_glove *h, const double *W, const double *b
     CYMF_TRY(use_device(h->device));
     if (h->dtype == CYMF_F32) CYMF_TRY(glove_upload(h, h->f32, W, bias, Wc, bias_c));
     else CYMF_TRY(glove_upload(h, h->f64, W, bias, Wc, bias_c));
+    if (h->step_path) {
+        CYMF_TRY(h->bW2.alloc((size_t)h->V));
+        CYMF_TRY(h->bH2.alloc((size_t)h->V));
+        hipLaunchKernelGGL(pack2_kernel, dim3(ew_blocks(h->V)), dim3(256), 0, h->stream, h->f32.bW.p, h->f32.abW.p, h->bW2.p, (int64_t)h->V);
+        hipLaunchKernelGGL(pack2_kernel, dim3(ew_blocks(h->V)), dim3(256), 0, h->stream, h->f32.bH.p, h->f32.abH.p, h->bH2.p, (int64_t)h->V);
+        CYMF_HIP(hipGetLastError());
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+    }
     h->have_params = true;
     return 0;
 }
@@ -490,6 +738,11 @@ extern "C" int cymf_glove_download(cymf_glove *h, double *W, double *bias, doubl
     if (!h || !W || !bias || !Wc || !bias_c || !h->have_params) return fail(CYMF_ERR_INVALID, "cymf_glove_download: bad arguments / no params");
     CYMF_TRY(use_device(h->device));
     const size_t nW = (size_t)h->V * h->K, nH = (size_t)h->Vc * h->K;
+    if (h->step_path) {
+        hipLaunchKernelGGL(unpack2_kernel, dim3(ew_blocks(h->V)), dim3(256), 0, h->stream, h->bW2.p, h->f32.bW.p, h->f32.abW.p, (int64_t)h->V);
+        hipLaunchKernelGGL(unpack2_kernel, dim3(ew_blocks(h->V)), dim3(256), 0, h->stream, h->bH2.p, h->f32.bH.p, h->f32.abH.p, (int64_t)h->V);
+        CYMF_HIP(hipGetLastError());
+    }
     if (h->dtype == CYMF_F32) {
         CYMF_TRY(download_f64(h->f32.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f32.bW, bias, (size_t)h->V, h->stream));
         CYMF_TRY(download_f64(h->f32.H, Wc, nH, h->stream)); CYMF_TRY(download_f64(h->f32.bH, bias_c, (size_t)h->V, h->stream));
@@ -508,7 +761,21 @@ static int glove_epoch(cymf_glove *h, GloveStore<T> &st, double *loss_out) {
     d.K = h->K; d.lr = (T)h->lr; d.x_max = (T)h->x_max; d.alpha = (T)h->alpha;
     CYMF_TRY(h->d_loss.zero(h->stream));
     if (h->N > 0) {
-        if (h->mode == CYMF_MODE_THROUGHPUT) {
+        if (h->mode == CYMF_MODE_THROUGHPUT && h->step_path) {
+            if constexpr (sizeof(T) == 4) {
+                GloveStepDev r;
+                r.W = reinterpret_cast<float *>(st.W.p); r.H = reinterpret_cast<float *>(st.H.p);
+                r.aW = reinterpret_cast<float *>(st.aW.p); r.aH = reinterpret_cast<float *>(st.aH.p);
+                r.bW2 = h->bW2.p; r.bH2 = h->bH2.p;
+                r.K = h->K; r.lr = (float)h->lr; r.x_max = (float)h->x_max; r.alpha = (float)h->alpha;
+                const int64_t chunks = (h->N + 63) / 64;
+                int64_t waves = std::max<int64_t>(1, std::min(chunks, h->step_waves));
+                const int64_t cpw = (chunks + waves - 1) / waves;
+                waves = (chunks + cpw - 1) / cpw;
+                launch_glove_step(h->K, r, h->d_central.p, h->d_context.p, reinterpret_cast<const float *>(st.counts.p), h->N, cpw,
+                                  h->d_loss.p, (int)((waves + 3) / 4), h->stream);
+            }
+        } else if (h->mode == CYMF_MODE_THROUGHPUT) {
             launch_glove<T>(h->K, d, h->d_central.p, h->d_context.p, st.counts.p, h->N, h->d_loss.p, hogwild_grid(h->N, h->f_max), h->stream);
         } else {
             for (size_t lv = 1; lv + 1 < h->level_off.size(); ++lv) {
