@@ -17,6 +17,7 @@
 #include "store.h"
 
 namespace cymf {
+struct WmfSeg { int32_t slot, begin, end, pad; };   // segment of a long row (see wmf_row_mfma_kernel)
 namespace {
 
 constexpr int WMF_THREADS = 256;
@@ -66,40 +67,47 @@ __global__ void wmf_add_diag_kernel(T *G, int K, T lambda) {
 __device__ __forceinline__ float dsqrt(float x) { return __fsqrt_rn(x); }
 __device__ __forceinline__ double dsqrt(double x) { return sqrt(x); }
 
-// In-LDS Cholesky A = L L^T (lower, in place) and solve of A x = b; A is [K][lda].
+// In-LDS Cholesky A = L L^T (lower, in place) and solve of A x = b; A is [K][lda], lda = K+1
+// (odd stride: a column walk touches every LDS bank once).  Two barriers per column in the
+// factorization (scale column c; rank-1 update of the trailing lower triangle on a 16x16 thread
+// tile, no integer division); the two triangular solves run on wavefront 0 alone with b in LDS, so
+// they need no workgroup barrier at all (LDS operations of one wavefront complete in program order).
 template <typename T>
-__device__ void chol_solve_lds(T *A, T *b, int K, int lda) {
+__device__ void chol_solve_lds(T *A, T *b, T *dg, int K, int lda) {
     const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
     for (int c = 0; c < K; ++c) {
-        if (tid == 0) A[c * lda + c] = dsqrt(A[c * lda + c]);
-        __syncthreads();
-        const T inv = (T)1 / A[c * lda + c];
+        __syncthreads();                         // trailing update of column c-1 is complete
+        const T dcc = A[c * lda + c];
+        const T inv = (T)1 / dsqrt(dcc);
+        if (tid == 0) dg[c] = dsqrt(dcc);        // the pivot itself stays in place: nobody waits to overwrite it
         for (int r = c + 1 + tid; r < K; r += WMF_THREADS) A[r * lda + c] *= inv;
         __syncthreads();
-        // trailing update of the lower triangle: A[r][q] -= A[r][c] A[q][c], c < q <= r < K
-        const int m = K - c - 1;
-        for (int e = tid; e < m * m; e += WMF_THREADS) {
-            const int r = c + 1 + e / m, q = c + 1 + e % m;
-            if (q <= r) A[r * lda + q] -= A[r * lda + c] * A[q * lda + c];
+        // A[r][q] -= L[r][c] L[q][c] for c < q <= r < K
+        for (int r = c + 1 + ty; r < K; r += 16) {
+            const T lrc = A[r * lda + c];
+            for (int q = c + 1 + tx; q <= r; q += 16) A[r * lda + q] -= lrc * A[q * lda + c];
         }
-        __syncthreads();
     }
-    // L z = b
-    for (int c = 0; c < K; ++c) {
-        if (tid == 0) b[c] /= A[c * lda + c];
-        __syncthreads();
-        const T bc = b[c];
-        for (int r = c + 1 + tid; r < K; r += WMF_THREADS) b[r] -= A[r * lda + c] * bc;
-        __syncthreads();
+    __syncthreads();
+    if (tid < 64) {
+        // lanes of ONE wavefront exchange b through LDS without a barrier: volatile keeps the compiler from
+        // caching or reordering these accesses (the hardware executes a wave's LDS operations in order)
+        volatile T *vb = b;
+        // L z = b
+        for (int c = 0; c < K; ++c) {
+            const T bc = vb[c] / dg[c];
+            for (int r = c + 1 + tid; r < K; r += 64) vb[r] = vb[r] - A[r * lda + c] * bc;
+            if (tid == 0) vb[c] = bc;
+        }
+        // L^T x = z
+        for (int c = K - 1; c >= 0; --c) {
+            const T bc = vb[c] / dg[c];
+            for (int r = tid; r < c; r += 64) vb[r] = vb[r] - A[c * lda + r] * bc;
+            if (tid == 0) vb[c] = bc;
+        }
     }
-    // L^T x = z
-    for (int c = K - 1; c >= 0; --c) {
-        if (tid == 0) b[c] /= A[c * lda + c];
-        __syncthreads();
-        const T bc = b[c];
-        for (int r = tid; r < c; r += WMF_THREADS) b[r] -= A[c * lda + r] * bc;
-        __syncthreads();
-    }
+    __syncthreads();
 }
 
 // Generic row kernel (any K <= 128, f32 or f64).
@@ -112,7 +120,8 @@ __global__ __launch_bounds__(WMF_THREADS) void wmf_row_kernel(int32_t rows, int 
     const int lda = K + 1;
     T *A = reinterpret_cast<T *>(smem_raw);   // [K][K+1]
     T *b = A + K * lda;                        // [K]
-    T *tile = b + K;                           // [WMF_TILE][K]
+    T *dg = b + K;                             // [K] Cholesky diagonal
+    T *tile = dg + K;                          // [WMF_TILE][K]
     const int tid = threadIdx.x;
     const int KK = K * K;
     for (int32_t i = blockIdx.x; i < rows; i += gridDim.x) {
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(WMF_THREADS) void wmf_row_kernel(int32_t rows, int 
             }
         }
         __syncthreads();
-        chol_solve_lds<T>(A, b, K, lda);                        // wmf.pyx:168
+        chol_solve_lds<T>(A, b, dg, K, lda);                    // wmf.pyx:168
         for (int k = tid; k < K; k += WMF_THREADS) X[(int64_t)i * K + k] = b[k];   // wmf.pyx:170-171
     }
 }
@@ -156,11 +165,18 @@ __global__ __launch_bounds__(WMF_THREADS) void wmf_row_kernel(int32_t rows, int 
 // are read directly from the gathered rows: lane l loads y[row_{2s + (l>>5)}][32*tile + (l&31)].
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int T32>
+// Work items: item s < n_segs is segment s of a LONG row (see below); item n_segs + r is row r in full
+// (rows longer than long_threshold are skipped there).  A segment is seg = {row slot, begin, end}: its partial Gramian and
+// partial sum are ADDED to scratch[slot] (K*K + K floats per long row, zeroed by the host) and the
+// solve is left to wmf_long_finish_kernel.  A row of 10^5 entries is thus built by ~50 workgroups
+// instead of being one workgroup's serial tail.
+template <int T32, bool SEG>
 __global__ __launch_bounds__(WMF_THREADS) void wmf_row_mfma_kernel(int32_t rows, const int32_t *__restrict__ indptr,
                                                                   const int32_t *__restrict__ indices,
                                                                   float *__restrict__ X, const float *__restrict__ Y,
-                                                                  const float *__restrict__ A0, float weight) {
+                                                                  const float *__restrict__ A0, float weight,
+                                                                  int32_t long_threshold, const WmfSeg *__restrict__ segs,
+                                                                  int32_t n_segs, float *__restrict__ scratch) {
     constexpr int K = 32 * T32;
     constexpr int NT = T32 * (T32 + 1) / 2;          // upper-triangular tiles
     constexpr int TPW = (NT + 3) / 4;                // tiles per wave
@@ -168,14 +184,25 @@ __global__ __launch_bounds__(WMF_THREADS) void wmf_row_mfma_kernel(int32_t rows,
     extern __shared__ unsigned char smem_raw[];
     float *A = reinterpret_cast<float *>(smem_raw);  // [K][K+1]
     float *b = A + K * lda;                           // [K]
+    float *dg = b + K;                                // [K] Cholesky diagonal
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
 
-    for (int32_t i = blockIdx.x; i < rows; i += gridDim.x) {
-        const int32_t p0 = indptr[i], p1 = indptr[i + 1];
-        if (p0 == p1) {
-            for (int k = tid; k < K; k += WMF_THREADS) X[(int64_t)i * K + k] = 0;
-            continue;
+    const int32_t n_items = SEG ? n_segs : rows;    // two instantiations: whole rows / segments of long rows
+    for (int32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        constexpr bool whole = !SEG;
+        const int32_t i = whole ? item : 0;
+        int32_t p0, p1, slot = -1;
+        if (whole) {
+            p0 = indptr[i]; p1 = indptr[i + 1];
+            if (p0 == p1) {
+                for (int k = tid; k < K; k += WMF_THREADS) X[(int64_t)i * K + k] = 0;
+                continue;
+            }
+            if (long_threshold > 0 && p1 - p0 > long_threshold) continue;   // built from segments
+        } else {
+            const WmfSeg sg = segs[item];
+            slot = sg.slot; p0 = sg.begin; p1 = sg.end;
         }
         __syncthreads();
         f32x16 acc[TPW];
@@ -226,6 +253,26 @@ __global__ __launch_bounds__(WMF_THREADS) void wmf_row_mfma_kernel(int32_t rows,
                 }
             }
         }
+        if constexpr (!whole) {   // segment of a long row: add the partial sums, no solve here
+            float *G = scratch + (size_t)slot * (K * K + K);
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                if (wave + 4 * q < NT) {
+                    if (tm[q] == tn[q]) {
+                        const float tot = bsum[q] + __shfl_xor(bsum[q], 32, 64);
+                        if (lh == 0) atomicAdd(G + K * K + 32 * tm[q] + li, tot);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * tm[q] + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int col = 32 * tn[q] + li;
+                        atomicAdd(G + row * K + col, acc[q][r]);
+                        if (tm[q] != tn[q]) atomicAdd(G + col * K + row, acc[q][r]);
+                    }
+                }
+            }
+            continue;
+        }
         // b = w * sum_j y_j, from the diagonal tiles' A operands (two half-waves = two rows per step)
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
@@ -249,9 +296,28 @@ __global__ __launch_bounds__(WMF_THREADS) void wmf_row_mfma_kernel(int32_t rows,
             }
         }
         __syncthreads();
-        chol_solve_lds<float>(A, b, K, lda);
+        if (weight > -1e30f) chol_solve_lds<float>(A, b, dg, K, lda);   // (a huge negative weight is the no-solve timing probe)
         for (int k = tid; k < K; k += WMF_THREADS) X[(int64_t)i * K + k] = b[k];
     }
+}
+
+// long rows: A = A0 + (w-1) G, b = w * sum, both from the scratch the segments accumulated
+__global__ __launch_bounds__(WMF_THREADS) void wmf_long_finish_kernel(int K, const int32_t *__restrict__ long_rows,
+                                                                     float *__restrict__ X, const float *__restrict__ A0,
+                                                                     const float *__restrict__ scratch, float weight) {
+    extern __shared__ unsigned char smem_raw[];
+    const int lda = K + 1;
+    float *A = reinterpret_cast<float *>(smem_raw);
+    float *b = A + K * lda;
+    float *dg = b + K;
+    const int tid = threadIdx.x;
+    const int32_t i = long_rows[blockIdx.x];
+    const float *G = scratch + (size_t)blockIdx.x * (K * K + K);
+    for (int e = tid; e < K * K; e += WMF_THREADS) A[(e / K) * lda + (e % K)] = A0[e] + (weight - 1.0f) * G[e];
+    for (int k = tid; k < K; k += WMF_THREADS) b[k] = weight * G[K * K + k];
+    __syncthreads();
+    chol_solve_lds<float>(A, b, dg, K, lda);
+    for (int k = tid; k < K; k += WMF_THREADS) X[(int64_t)i * K + k] = b[k];
 }
 
 }  // namespace
@@ -274,6 +340,16 @@ struct cymf_wmf {
     DevBuf<int32_t> d_indptr, d_indices, d_tindptr, d_tindices;
     bool have_data = false, have_params = false;
     bool use_mfma = true;
+    // rows with more than long_threshold entries are built from segments (MFMA path)
+    int32_t long_threshold = 2048;
+    DevBuf<cymf::WmfSeg> d_segs[2];
+    DevBuf<int32_t> d_long_rows[2];
+    int32_t n_segs[2] = {0, 0}, n_long[2] = {0, 0};
+    DevBuf<float> d_scratch;
+    // YtY on the MFMA path: identity index list and segments over the rows of each table (0 = W, 1 = H)
+    DevBuf<int32_t> d_iota;
+    DevBuf<cymf::WmfSeg> d_gram_segs[2];
+    int32_t n_gram_segs[2] = {0, 0};
 };
 
 template <typename F>
@@ -291,36 +367,77 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
     const T *Y = side == 0 ? st.H.p : st.W.p;
     const int32_t *ip = side == 0 ? h->d_indptr.p : h->d_tindptr.p;
     const int32_t *ix = side == 0 ? h->d_indices.p : h->d_tindices.p;
-    CYMF_TRY(st.G.alloc((size_t)K * K));
+    CYMF_TRY(st.G.alloc((size_t)K * K + K));   // K*K Gramian (+ K: the column sums the MFMA path also produces)
     CYMF_TRY(st.G.zero(h->stream));
-    {   // YtY + lambda I  (wmf.pyx:142-143)
+    const bool mfma_ok = sizeof(T) == 4 && h->use_mfma && K % 32 == 0 && K <= 128;
+    if (mfma_ok) {
+        // YtY on the MFMA units: Y as ONE long "row" over the identity index list, cut into segments, each
+        // workgroup adding its partial 32x32 tiles into G (the segment instantiation of the row kernel)
+        if constexpr (sizeof(T) == 4) {
+            const int g = side == 0 ? 1 : 0;   // Y is the item table for the user sweep and vice versa
+            size_t smem = sizeof(float) * ((size_t)K * (K + 1) + 2 * K);
+            const int ns = h->n_gram_segs[g];
+#define WMF_GRAM_(T32_)                                                                                                       \
+    do {                                                                                                                      \
+        CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, true>, smem));                                                           \
+        hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(ns), dim3(WMF_THREADS), smem, h->stream, 0, nullptr,        \
+                           h->d_iota.p, nullptr, reinterpret_cast<const float *>(Y), nullptr, 0.0f, 0, h->d_gram_segs[g].p, ns, \
+                           reinterpret_cast<float *>(st.G.p));                                                                \
+    } while (0)
+            switch (K / 32) {
+            case 1: WMF_GRAM_(1); break;
+            case 2: WMF_GRAM_(2); break;
+            case 3: WMF_GRAM_(3); break;
+            default: WMF_GRAM_(4); break;
+            }
+#undef WMF_GRAM_
+        }
+    } else {   // YtY + lambda I  (wmf.pyx:142-143)
         int grid = (int)std::min<int64_t>(((int64_t)cols + WMF_TILE - 1) / WMF_TILE, 1024);
         size_t smem = sizeof(T) * WMF_TILE * K;
         hipLaunchKernelGGL(wmf_gram_kernel<T>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, Y, (int64_t)cols, K, st.G.p);
-        hipLaunchKernelGGL(wmf_add_diag_kernel<T>, dim3((K + 63) / 64), dim3(64), 0, h->stream, st.G.p, K, (T)h->wd);
-        CYMF_HIP(hipGetLastError());
     }
+    hipLaunchKernelGGL(wmf_add_diag_kernel<T>, dim3((K + 63) / 64), dim3(64), 0, h->stream, st.G.p, K, (T)h->wd);
+    CYMF_HIP(hipGetLastError());
     const int grid = (int)std::min<int64_t>(rows, 256 * 16);
     bool mfma = false;
     if constexpr (sizeof(T) == 4) {
         if (h->use_mfma && K % 32 == 0 && K <= 128) {
             mfma = true;
-            size_t smem = sizeof(float) * ((size_t)K * (K + 1) + K);
+            size_t smem = sizeof(float) * ((size_t)K * (K + 1) + 2 * K);
             const float *Yf = reinterpret_cast<const float *>(Y);
             float *Xf = reinterpret_cast<float *>(X);
             const float *Gf = reinterpret_cast<const float *>(st.G.p);
-            CYMF_TRY(allow_lds(wmf_row_mfma_kernel<1>, smem)); CYMF_TRY(allow_lds(wmf_row_mfma_kernel<2>, smem));
-            CYMF_TRY(allow_lds(wmf_row_mfma_kernel<3>, smem)); CYMF_TRY(allow_lds(wmf_row_mfma_kernel<4>, smem));
+            const int32_t nseg = h->n_segs[side], nlong = h->n_long[side];
+            const WmfSeg *segs = h->d_segs[side].p;
+            if (nlong > 0) CYMF_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)nlong * ((size_t)K * K + K) * sizeof(float), h->stream));
+            const int grid_seg = (int)std::min<int64_t>(nseg, 256 * 16);
+#define WMF_LAUNCH_(T32_)                                                                                                   \
+    do {                                                                                                                    \
+        CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, false>, smem));                                                        \
+        CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, true>, smem));                                                         \
+        if (nseg > 0)   /* segments of the long rows first: the longest work starts earliest */                             \
+            hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, rows, \
+                               ip, ix, Xf, Yf, Gf, (float)h->weight, h->long_threshold, segs, nseg, h->d_scratch.p);        \
+        hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, false>), dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, ip,    \
+                           ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, segs, nseg, h->d_scratch.p); \
+    } while (0)
             switch (K / 32) {
-            case 1: hipLaunchKernelGGL(wmf_row_mfma_kernel<1>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, ip, ix, Xf, Yf, Gf, (float)h->weight); break;
-            case 2: hipLaunchKernelGGL(wmf_row_mfma_kernel<2>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, ip, ix, Xf, Yf, Gf, (float)h->weight); break;
-            case 3: hipLaunchKernelGGL(wmf_row_mfma_kernel<3>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, ip, ix, Xf, Yf, Gf, (float)h->weight); break;
-            default: hipLaunchKernelGGL(wmf_row_mfma_kernel<4>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, ip, ix, Xf, Yf, Gf, (float)h->weight); break;
+            case 1: WMF_LAUNCH_(1); break;
+            case 2: WMF_LAUNCH_(2); break;
+            case 3: WMF_LAUNCH_(3); break;
+            default: WMF_LAUNCH_(4); break;
+            }
+#undef WMF_LAUNCH_
+            if (nlong > 0) {
+                CYMF_TRY(allow_lds(wmf_long_finish_kernel, smem));
+                hipLaunchKernelGGL(wmf_long_finish_kernel, dim3(nlong), dim3(WMF_THREADS), smem, h->stream, K, h->d_long_rows[side].p, Xf, Gf,
+                                   h->d_scratch.p, (float)h->weight);
             }
         }
     }
     if (!mfma) {
-        size_t smem = sizeof(T) * ((size_t)K * (K + 1) + K + (size_t)WMF_TILE * K);
+        size_t smem = sizeof(T) * ((size_t)K * (K + 1) + 2 * K + (size_t)WMF_TILE * K);
         CYMF_TRY(allow_lds(wmf_row_kernel<T>, smem));
         hipLaunchKernelGGL(wmf_row_kernel<T>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, K, ip, ix, X, Y, st.G.p, (T)h->weight);
     }
@@ -340,6 +457,7 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     h->U = U; h->I = I; h->K = K; h->weight = weight; h->wd = weight_decay; h->dtype = dtype; h->device = device;
     const char *env = getenv("CYMF_WMF_NO_MFMA");
     h->use_mfma = !(env && env[0] == '1');
+    if (const char *e2 = getenv("CYMF_WMF_LONG")) h->long_threshold = std::max(64, atoi(e2));
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     *out = h;
@@ -367,6 +485,40 @@ extern "C" int cymf_wmf_set_data(cymf_wmf *h, const int32_t *indptr, const int32
     CYMF_TRY(h->d_indices.upload(indices, (size_t)nnz, h->stream));
     CYMF_TRY(h->d_tindptr.upload(t_indptr, (size_t)h->I + 1, h->stream));
     CYMF_TRY(h->d_tindices.upload(t_indices, (size_t)nnz, h->stream));
+    // long rows -> segments of long_threshold entries (both sides)
+    size_t max_long = 0;
+    for (int side = 0; side < 2; ++side) {
+        const int32_t *ip = side == 0 ? indptr : t_indptr;
+        const int32_t rows = side == 0 ? h->U : h->I;
+        std::vector<WmfSeg> segs;
+        std::vector<int32_t> longs;
+        for (int32_t r = 0; r < rows; ++r) {
+            const int32_t n = ip[r + 1] - ip[r];
+            if (n <= h->long_threshold) continue;
+            const int32_t slot = (int32_t)longs.size();
+            longs.push_back(r);
+            for (int32_t b = ip[r]; b < ip[r + 1]; b += h->long_threshold)
+                segs.push_back(WmfSeg{slot, b, std::min(b + h->long_threshold, ip[r + 1]), 0});
+        }
+        h->n_segs[side] = (int32_t)segs.size();
+        h->n_long[side] = (int32_t)longs.size();
+        CYMF_TRY(h->d_segs[side].upload(segs.data(), segs.size(), h->stream));
+        CYMF_TRY(h->d_long_rows[side].upload(longs.data(), longs.size(), h->stream));
+        max_long = std::max(max_long, longs.size());
+    }
+    CYMF_TRY(h->d_scratch.alloc(std::max<size_t>(1, max_long * ((size_t)h->K * h->K + h->K))));
+    {
+        std::vector<int32_t> iota((size_t)std::max(h->U, h->I));
+        for (size_t v = 0; v < iota.size(); ++v) iota[v] = (int32_t)v;
+        CYMF_TRY(h->d_iota.upload(iota.data(), iota.size(), h->stream));
+        for (int g = 0; g < 2; ++g) {
+            const int32_t n = g == 0 ? h->U : h->I;
+            std::vector<WmfSeg> segs;
+            for (int32_t b = 0; b < n; b += 512) segs.push_back(WmfSeg{0, b, std::min(b + 512, n), 0});
+            h->n_gram_segs[g] = (int32_t)segs.size();
+            CYMF_TRY(h->d_gram_segs[g].upload(segs.data(), segs.size(), h->stream));
+        }
+    }
     CYMF_HIP(hipStreamSynchronize(h->stream));
     h->have_data = true;
     return 0;
