@@ -34,6 +34,18 @@ from cymf_amd.bpr import BprTrainer  # noqa: E402
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md chip table
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the cgroup quota (cpu.max) if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -144,7 +156,7 @@ def main():
         rate1 = (n - om.skipped) / dt1
         om.close()
         # (2) the reference's HOGWILD regime (prange over lock-free W/H, cymf/bpr.pyx:162) on all host cores
-        cores = oracle.max_threads()
+        cores = min(oracle.max_threads(), host_cpu_share())
         om = oracle.Bpr(W0.copy(), H0.copy(), args.optimizer, lr, wd)
         reps = max(1, min(8, cores // 2))        # keep the leg at roughly the single-thread leg's duration
         tc = time.perf_counter()
