@@ -67,7 +67,7 @@ def main():
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = local
+    device = local if os.environ.get("CYMF_BENCH_SAME_DEVICE") != "1" else 0   # (test hook: all ranks on device 0)
     U, I, nnz, K, seed = synthetic.CONFIGS[args.config]
     if args.scale != 1.0:
         U, nnz = max(int(U * args.scale), 1000), max(int(nnz * args.scale), 10000)

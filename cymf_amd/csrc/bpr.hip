@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     // (AdaGrad/Adam: a run belongs to one wave, see the host side)
     const bool shared_runs = wave_ranges == nullptr;
     if (wave >= n_waves) return;
+    const int64_t step_begin = slot_begin, step_end = slot_end;
     if (shared_runs) {
         const int64_t b0 = slot_begin + wave * chunks_per_wave * 64;
         const int64_t e0 = b0 + chunks_per_wave * 64;
@@ -262,6 +263,14 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     const int64_t c_begin = 0;
     const int64_t c_end = (slot_end - slot_begin + 63) >> 6;
     if (c_end <= 0) return;
+    // only the first and the last item run of the range can continue in another wave's range: runs
+    // strictly inside are owned by this wave alone and need no exchange at chunk boundaries
+    int shared_first = -1, shared_last = -1;
+    if (shared_runs) {
+        const int32_t fi = slot_item[slot_begin], li = slot_item[slot_end - 1];
+        if (slot_begin > step_begin && slot_item[slot_begin - 1] == fi) shared_first = fi;
+        if (slot_end < step_end && slot_item[slot_end] == li) shared_last = li;
+    }
     float loss_sum = 0.0f;
     unsigned int n_done = 0;
     float *const Ws[2] = {d.W0, d.W1};
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
             }
         }
         // chunk boundary: exchange the open item's progress with the other waves that share it
-        if (shared_runs && cur_item >= 0 && c + 1 < c_end) {
+        if (cur_item >= 0 && (cur_item == shared_first || cur_item == shared_last) && c + 1 < c_end) {
             exchange_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
             settle<RowT, R>(hi);
             settle<RowT, R>(hi0);

@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no libcymf_hip.so yet (built artefacts are git-ignored): build it once
+    from cymf_amd import _lib, build as hip_build
+    if not os.path.exists(_lib.SO_PATH):
+        hip_build.build(verbose=False)
 
 
 def golden(name):
