@@ -157,6 +157,11 @@ def main():
         om.close()
         # (2) the reference's HOGWILD regime (prange over lock-free W/H, cymf/bpr.pyx:162) on all host cores
         cores = min(oracle.max_threads(), host_cpu_share())
+        cpu_model = "unknown CPU"
+        try:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except Exception:
+            pass
         om = oracle.Bpr(W0.copy(), H0.copy(), args.optimizer, lr, wd)
         reps = max(1, min(8, cores // 2))        # keep the leg at roughly the single-thread leg's duration
         tc = time.perf_counter()
@@ -167,7 +172,14 @@ def main():
         om.close()
         cpu = {"value": done / dtn, "unit": "triplet-updates/s", "cores": cores, "kind": "port",
                "sample": f"first {n} triplets of the same shuffled order x{reps}, fp64, HOGWILD on {cores} threads, {dtn:.1f}s; "
-                         f"sequential 1-thread port: {rate1:.0f} triplet-updates/s ({dt1:.1f}s)"}
+                         f"sequential 1-thread port: {rate1:.0f} triplet-updates/s ({dt1:.1f}s); host: {cpu_model}, omp_get_max_threads()={oracle.max_threads()}"}
+
+    copy_gbps = None
+    if rank == 0 and world == 1:
+        try:
+            copy_gbps = _lib.stream_copy_gbps(device, 1 << 30, 10)
+        except Exception:
+            copy_gbps = None
 
     if rank == 0:
         out = {
@@ -190,7 +202,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": "bpr_step_kernel", "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launches,
-                         "bytes_per_unit": bytes_per_triplet},
+                         "bytes_per_unit": bytes_per_triplet, "stream_copy_GBps": copy_gbps},
             "cpu_baseline": cpu,
             "skipped_draws": int(s_after),
         }

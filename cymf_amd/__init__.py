@@ -6,8 +6,9 @@ from .wmf import WMF
 from .relmf import RelMF
 from .glove import GloVe
 from . import synthetic
+from . import dataset
 from .evaluator import Evaluator, AverageOverAllEvaluator, AoaEvaluator, UnbiasedEvaluator
 
 __version__ = "0.1.0"
 __all__ = ["BPR", "WMF", "RelMF", "GloVe", "Evaluator", "AverageOverAllEvaluator", "AoaEvaluator",
-           "UnbiasedEvaluator", "synthetic"]
+           "UnbiasedEvaluator", "synthetic", "dataset"]

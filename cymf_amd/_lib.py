@@ -37,6 +37,7 @@ def lib():
         "cymf_device_count": ([], ci),
         "cymf_device_name": ([ci, C.c_char_p, ci], ci),
         "cymf_device_sync": ([ci], ci),
+        "cymf_device_stream_copy_gbps": ([ci, i64, ci, vp], ci),
         "cymf_rng_fill_uniform": ([ci, u32, u64, i64, i64, vp], ci),
         "cymf_bpr_create": ([pp, i32, i32, i32, ci, f64, f64, u32, ci, ci, ci], ci),
         "cymf_bpr_set_data": ([vp, vp, vp, i64, vp, vp, vp, i64], ci),
@@ -121,6 +122,13 @@ def device_name(device=0):
 
 def device_sync(device=0):
     check(lib().cymf_device_sync(device))
+
+
+def stream_copy_gbps(device=0, nbytes=1 << 30, iters=10):
+    """Measured float4 stream-copy rate (read + write) in GB/s."""
+    out = C.c_double(0.0)
+    check(lib().cymf_device_stream_copy_gbps(device, int(nbytes), int(iters), C.byref(out)))
+    return out.value
 
 
 def rng_fill_uniform(seed, rng_range, n, skip=0, device=0):

@@ -72,3 +72,35 @@ extern "C" int cymf_device_sync(int device) {
     CYMF_HIP(hipDeviceSynchronize());
     return 0;
 }
+
+namespace {
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+}  // namespace
+
+extern "C" int cymf_device_stream_copy_gbps(int device, int64_t bytes, int iters, double *gbps_out) {
+    if (!gbps_out || bytes < (1 << 20) || iters < 1) return fail(CYMF_ERR_INVALID, "cymf_device_stream_copy_gbps: bad arguments");
+    CYMF_TRY(use_device(device));
+    const int64_t n = bytes / 16;
+    DevBuf<float4> a, b;
+    CYMF_TRY(a.alloc((size_t)n));
+    CYMF_TRY(b.alloc((size_t)n));
+    CYMF_HIP(hipMemset(a.p, 0, (size_t)n * 16));
+    hipEvent_t e0, e1;
+    CYMF_HIP(hipEventCreate(&e0));
+    CYMF_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, nullptr, a.p, b.p, n);   // warm-up
+    CYMF_HIP(hipEventRecord(e0, nullptr));
+    for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, nullptr, a.p, b.p, n);
+    CYMF_HIP(hipEventRecord(e1, nullptr));
+    CYMF_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    CYMF_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbps_out = 2.0 * (double)n * 16.0 * iters / (ms * 1e-3) / 1e9;
+    return 0;
+}

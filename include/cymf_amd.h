@@ -55,6 +55,9 @@ int cymf_version(void);
 int cymf_device_count(void);                                  /* replaces cymf::cpucount(), cymf/util.h:15 */
 int cymf_device_name(int device, char *buf, int buflen);
 int cymf_device_sync(int device);
+/* measured HBM rate of a float4 device-to-device stream copy (read + write bytes per second, in GB/s):
+ * the achievable-bandwidth yardstick printed beside the 8 TB/s datasheet peak */
+int cymf_device_stream_copy_gbps(int device, int64_t bytes, int iters, double *gbps_out);
 
 /* ---------------------------------------------------------------- negative-sample index stream
  * UniformGenerator(a=0, b=range, seed): cymf/math.pyx:12-18, cymf/math.pxd:31-39

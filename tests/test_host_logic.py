@@ -149,3 +149,42 @@ def test_synthetic_configs_have_the_stated_shape():
     assert X.has_sorted_indices and (X.data == 1.0).all()
     X2, _ = synthetic.config_matrix("C1")
     assert (X != X2).nnz == 0   # deterministic
+
+
+def test_movielens_local_loader(tmp_path):
+    pd = pytest.importorskip("pandas")
+    sk = pytest.importorskip("sklearn.model_selection")
+    from cymf_amd.dataset import MovieLens
+    with pytest.raises(ValueError):
+        MovieLens("ml-10b", root=tmp_path)                       # tests/test_dataset.py:18-20 of the reference
+    with pytest.raises(FileNotFoundError):
+        MovieLens("ml-100k", root=tmp_path)                      # never downloads
+    rs = np.random.RandomState(0)
+    n = 3000
+    users, items = rs.randint(1, 120, n) * 3, rs.randint(1, 200, n) * 2 + 1      # sparse ids -> reset_id matters
+    df = pd.DataFrame({"user": users, "item": items, "rating": rs.randint(1, 6, n), "timestamp": rs.randint(0, 10**9, n)})
+    df = df.drop_duplicates(["user", "item"])
+    (tmp_path / "ml-100k").mkdir()
+    df.to_csv(tmp_path / "ml-100k" / "u.data", sep="\t", header=False, index=False)
+    ds = MovieLens("ml-100k", root=tmp_path)
+    assert ds.train.shape == ds.valid.shape == ds.test.shape == (ds.num_user, ds.num_item)   # tests/test_dataset.py:15-16
+    assert ds.num_user == df.user.nunique() and ds.num_item == df.item.nunique()
+    pos = int((df.rating >= 4).sum())
+    assert ds.train_size + ds.valid_size + ds.test_size == pos
+    assert ds.test_size == int(np.ceil(0.1 * pos)) and ds.valid_size == int(np.ceil(0.1 * (pos - ds.test_size)))
+    # literal restatement of cymf/dataset/movielens.py:53-67 on the same file
+    ref = pd.read_csv(tmp_path / "ml-100k" / "u.data", sep="\t", names=("user", "item", "rating", "timestamp"))
+    for col in ("item", "user"):
+        m = {}
+        for x in set(ref[col]):
+            m.setdefault(x, len(m))
+        ref[col] = ref[col].map(lambda x: m[x])
+    ref = ref[ref["rating"] >= 4.0].copy()
+    ref["rating"] = 1.0
+    tr, te = sk.train_test_split(ref, test_size=0.1, random_state=12345)
+    tr, va = sk.train_test_split(tr, test_size=0.1, random_state=12345)
+    want = sparse.lil_matrix((ds.num_user, ds.num_item))
+    for u, i, r in zip(tr["user"].values, tr["item"].values, tr["rating"].values):
+        want[u, i] = r
+    assert (ds.train.tocsr() != want.tocsr()).nnz == 0
+    assert sorted(zip(te.user, te.item)) == sorted(zip(*ds.test.nonzero()))
