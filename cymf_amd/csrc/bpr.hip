@@ -17,6 +17,7 @@
 #include "store.h"
 
 #include <algorithm>
+#include <cmath>
 
 namespace cymf {
 
@@ -227,7 +228,7 @@ __device__ __forceinline__ void settle(RowT &a) {
     for (int r = 0; r < R; ++r) asm volatile("" : "+v"(a.v[r]));
 }
 
-template <int R, bool PACKED, int OPT, int PF>
+template <int R, bool PACKED, int OPT, int PF, int PFJ = PF>
 __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const int32_t *__restrict__ slot_user,
                                                       const int32_t *__restrict__ slot_item,
                                                       const int32_t *__restrict__ slot_neg, int64_t slot_begin,
@@ -296,18 +297,30 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     // triplets' loads are in flight (across chunk boundaries too) and PF triplets' stores are draining,
     // and no register that a pending store still reads is overwritten early -- hipcc guards such a
     // reuse with s_waitcnt vmcnt(N) (N = operations issued since), which at N ~ 0 drains the ring.
+    // The two rings may have different depths: user rows come from HBM (W does not fit the Infinity
+    // Cache) and want a long lead (PF), negative rows come from the cache-resident H and get a short one
+    // (PFJ), which also shortens their read-modify-write window (fewer HOGWILD collisions per wave).
     constexpr int RING = 2 * PF;
-    static_assert(64 % RING == 0, "ring must divide the chunk");
-    RowT wq[RING], jq[RING], swq[RING][NSA], sjq[RING][NSA];
-    auto issue = [&](int p, int32_t u, int32_t j) {
-        const int64_t ou = (int64_t)u * K, oj = (int64_t)(j < 0 ? 0 : (j & 0x3fffffff)) * K;
+    constexpr int RINGJ = 2 * PFJ;
+    constexpr int XCHG = RING > 32 ? RING : 32;   // slots between exchanges of a shared item run
+    static_assert(64 % RING == 0 && RING % RINGJ == 0, "rings must divide the chunk and each other");
+    RowT wq[RING], jq[RINGJ], swq[RING][NSA], sjq[RINGJ][NSA];
+    auto issue_w = [&](int p, int32_t u) {
+        const int64_t ou = (int64_t)u * K;
         wq[p].load(d.W + ou, K, lane);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) swq[p][q].load(Ws[q] + ou, K, lane);
+    };
+    auto issue_j = [&](int p, int32_t j) {
+        const int64_t oj = (int64_t)(j < 0 ? 0 : (j & 0x3fffffff)) * K;
         jq[p].load(d.H + oj, K, lane);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) { swq[p][q].load(Ws[q] + ou, K, lane); sjq[p][q].load(Hs[q] + oj, K, lane); }
+        for (int q = 0; q < NS; ++q) sjq[p][q].load(Hs[q] + oj, K, lane);
     };
 #pragma unroll
-    for (int p = 0; p < PF; ++p) issue(p, bcast_lane(u_c, p), bcast_lane(j_c, p));
+    for (int p = 0; p < PF; ++p) issue_w(p, bcast_lane(u_c, p));
+#pragma unroll
+    for (int p = 0; p < PFJ; ++p) issue_j(p, bcast_lane(j_c, p));
 
     int cur_item = -1;
     RowT hi, hi0, shi[NSA];
@@ -344,8 +357,9 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
 #pragma unroll
                         for (int q = 0; q < NS; ++q) settle<RowT, R>(shi[q]);
                     }
-                    const RowT hj_old = jq[p];
-                    loss_sum += bpr_update_rows<float, R, PACKED, OPT, true>(d, wq[p], hi, jq[p], swq[p], shi, sjq[p]);
+                    const int pj = p % RINGJ;
+                    const RowT hj_old = jq[pj];
+                    loss_sum += bpr_update_rows<float, R, PACKED, OPT, true>(d, wq[p], hi, jq[pj], swq[p], shi, sjq[pj]);
                     if (!(diag & 2)) wq[p].store(d.W + (int64_t)u * K, K, lane);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) swq[p][q].store(Ws[q] + (int64_t)u * K, K, lane);
@@ -353,25 +367,26 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
                     // positive-side deltas land every few microseconds -- gets its delta added atomically,
                     // so that this write cannot undo them
                     if (hot || (diag & 4)) {
-                        if (!(diag & 1)) atomic_add_row<RowT, R>(d.H + (int64_t)j * K, jq[p], hj_old, K, lane);
+                        if (!(diag & 1)) atomic_add_row<RowT, R>(d.H + (int64_t)j * K, jq[pj], hj_old, K, lane);
                     } else {
-                        jq[p].store(d.H + (int64_t)j * K, K, lane);
+                        jq[pj].store(d.H + (int64_t)j * K, K, lane);
                     }
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) sjq[p][q].store(Hs[q] + (int64_t)j * K, K, lane);
+                    for (int q = 0; q < NS; ++q) sjq[pj][q].store(Hs[q] + (int64_t)j * K, K, lane);
                 }
-                // refill the entry PF ahead with slot t + PF (of this chunk or the next one)
-                const int tn = t + PF;
-                const int32_t nu = tn < 64 ? bcast_lane(u_c, tn & 63) : bcast_lane(u_n, tn & 63);
-                const int32_t nj = tn < 64 ? bcast_lane(j_c, tn & 63) : bcast_lane(j_n, tn & 63);
-                issue((p + PF) % RING, nu, nj);
+                // refill the entries PF / PFJ ahead with the rows of slots t + PF / t + PFJ (this chunk or the next)
+                const int tw = t + PF, tj = t + PFJ;
+                issue_w((p + PF) % RING, tw < 64 ? bcast_lane(u_c, tw & 63) : bcast_lane(u_n, tw & 63));
+                issue_j((p + PFJ) % RINGJ, tj < 64 ? bcast_lane(j_c, tj & 63) : bcast_lane(j_n, tj & 63));
             }
-        }
-        // chunk boundary: exchange the open item's progress with the other waves that share it
-        if (cur_item >= 0 && (cur_item == shared_first || cur_item == shared_last) && c + 1 < c_end) {
-            exchange_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
-            settle<RowT, R>(hi);
-            settle<RowT, R>(hi0);
+            // every XCHG slots: exchange the open item's progress with the other waves that share its run.
+            // The delta-sum of c concurrent waves is stable while c * (1 - (1 - lr*wd)^XCHG) < 1, so a shorter
+            // interval buys a proportionally larger safe number of wavefronts.
+            if ((t0 + RING) % XCHG == 0 && cur_item >= 0 && (cur_item == shared_first || cur_item == shared_last)) {
+                exchange_row<RowT, R>(d.H + (int64_t)cur_item * K, hi, hi0, K, lane);
+                settle<RowT, R>(hi);
+                settle<RowT, R>(hi0);
+            }
         }
         u_c = u_n; i_c = i_n; j_c = j_n;
         load_meta(c + 2, u_n, i_n, j_n);
@@ -535,11 +550,12 @@ struct cymf_bpr {
 
     // throughput mode
     int32_t steps_per_epoch = 1;
-    int32_t max_waves = 256 * 8;          // hardware side: 8 wavefronts per CU
+    int32_t max_waves = 256 * 12;         // hardware side: 12 wavefronts per CU (measured plateau on C3)
+    double f_item_max = 0.0;              // share of the triplets that carry the most popular positive item
     int32_t rows_per_inflight = 8;        // staleness bound: table rows per row in flight
     bool item_aligned = false;            // experiment: AdaGrad/Adam item runs owned by one wave (CYMF_BPR_ITEM_ALIGNED=1)
     int32_t adaptive_rpi_factor = 2;      // AdaGrad/Adam: stricter rows-in-flight bound (state RMW is not atomic)
-    int32_t step_pf = 8;                  // prefetch ring depth of the step kernel (8 or 16)
+    int32_t step_pf = 84;                 // prefetch ring depth of the step kernel (8 or 16)
     int32_t xcd_stride = 1;               // diagnostic (CYMF_BPR_XCD_STRIDE=8: all active blocks on one XCD)
     std::vector<int64_t> step_off;           // slot offsets, steps_per_epoch+1
     DevBuf<int32_t> d_slot_user, d_slot_item, d_slot_neg[2];   // slot_neg double-buffered by epoch parity
@@ -611,14 +627,14 @@ void launch_level(int K, int opt, const BprDev<T> &d, const int32_t *tu, const i
 
 
 
-template <int R, bool PACKED, int STEP_PF>
+template <int R, bool PACKED, int STEP_PF, int STEP_PFJ = STEP_PF>
 void launch_step_opt(int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn,
                      int64_t b, int64_t e, int64_t cpw, int xs, const int64_t *wr, int64_t nw, double *loss, unsigned long long *perf, int grid_blocks, hipStream_t s) {
     dim3 grid(grid_blocks * (xs & 255)), block(256);
     switch (opt) {
-    case CYMF_OPT_SGD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_SGD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
-    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
-    default: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAM, STEP_PF>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_SGD, STEP_PF, STEP_PFJ>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, STEP_PF, STEP_PFJ>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
+    default: hipLaunchKernelGGL((bpr_step_kernel<R, PACKED, CYMF_OPT_ADAM, STEP_PF, STEP_PFJ>), grid, block, 0, s, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf); break;
     }
 }
 
@@ -631,8 +647,10 @@ void launch_step_pf(int opt, const BprDev<float> &d, const int32_t *su, const in
     } else if (opt == CYMF_OPT_ADAM) {   // 6 rows per entry
         launch_step_opt<R, PACKED, 4>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
     } else {
-        (void)pf;
-        launch_step_opt<R, PACKED, 8>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
+        if (opt == CYMF_OPT_SGD && pf == 164) launch_step_opt<R, PACKED, 16, 4>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
+        else if (opt == CYMF_OPT_SGD && pf == 168) launch_step_opt<R, PACKED, 16, 8>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
+        else if (opt == CYMF_OPT_SGD && pf == 84) launch_step_opt<R, PACKED, 8, 4>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
+        else launch_step_opt<R, PACKED, 8>(opt, d, su, si, sn, b, e, cpw, xs, wr, nw, loss, perf, grid_blocks, s);
     }
 }
 
@@ -820,8 +838,17 @@ int run_one_step(cymf_bpr *h) {
         int64_t waves = std::min<int64_t>(chunks, h->max_waves);
         // adaptive optimizers carry per-row state whose read-modify-write is not atomic: 4x stricter
         const int64_t rpi = (int64_t)h->rows_per_inflight * (h->opt == CYMF_OPT_SGD ? 1 : h->adaptive_rpi_factor);
-        const int64_t by_rows = std::max<int64_t>(1, std::min(h->U, h->I) / (rpi * (h->K > 128 || h->opt == CYMF_OPT_ADAM ? 4 : h->step_pf)));
+        const bool narrow = h->K > 128 || h->opt == CYMF_OPT_ADAM;
+        const int pf_w = narrow ? 4 : (h->step_pf > 100 ? 16 : 8);                       // lead of the user-row ring
+        const int pf_j = narrow ? 4 : (h->step_pf > 10 ? h->step_pf % 10 : h->step_pf);  // lead of the negative-row ring
+        const int64_t by_rows = std::max<int64_t>(1, std::min<int64_t>(h->I / (rpi * pf_j), h->U / (rpi * pf_w)));
         waves = std::max<int64_t>(1, std::min(waves, by_rows));
+        // delta-sum exchange of a run shared by c = waves * f_max wavefronts contracts by (1 - lr*wd)^32 per wave and
+        // interval: keep c * (1 - (1 - lr*wd)^32) <= 1/2 (measured: 0.49 trains like the sequential run, 0.65 degrades)
+        if (h->opt == CYMF_OPT_SGD && h->f_item_max > 0 && h->lr * h->wd > 0) {
+            const double shrink = 1.0 - std::pow(1.0 - std::min(h->lr * h->wd, 0.5), 32.0);
+            waves = std::max<int64_t>(1, std::min<int64_t>(waves, (int64_t)(0.5 / (h->f_item_max * shrink))));
+        }
         int64_t cpw = (chunks + waves - 1) / waves;
         waves = (chunks + cpw - 1) / cpw;
         const int64_t *wave_ranges = nullptr;
@@ -888,6 +915,11 @@ int build_throughput_layout(cymf_bpr *h) {
     std::vector<int64_t> cnt((size_t)h->I + 1, 0);
     for (int64_t l = 0; l < N; ++l) cnt[(size_t)h->h_pos_items[l] + 1]++;
     for (int32_t i = 0; i < h->I; ++i) cnt[i + 1] += cnt[i];
+    {
+        int64_t mx = 0;
+        for (int32_t i = 0; i < h->I; ++i) mx = std::max(mx, cnt[i + 1] - cnt[i]);
+        h->f_item_max = N > 0 ? (double)mx / (double)N : 0.0;
+    }
     {   // hot items: at least hot_threshold positives per step (cnt[] holds the bucket ends here)
         std::vector<uint32_t> bits(((size_t)h->I + 31) / 32, 0u);
         int64_t prev = 0;
@@ -991,6 +1023,7 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
     }
     if (const char *e3 = getenv("CYMF_BPR_XCD_STRIDE")) h->xcd_stride = std::max(1, atoi(e3));
     if (const char *e4 = getenv("CYMF_BPR_DIAG")) h->xcd_stride |= atoi(e4) << 8;
+    if (const char *e6 = getenv("CYMF_BPR_PF")) h->step_pf = atoi(e6);   // 8 (default), 84, 164, 168 = (PF, PFJ) pairs
     if (const char *e7 = getenv("CYMF_BPR_ITEM_ALIGNED")) h->item_aligned = e7[0] == '1';
     if (const char *e8 = getenv("CYMF_BPR_ADAPTIVE_RPI")) h->adaptive_rpi_factor = std::max(1, atoi(e8));
     if (const char *e5 = getenv("CYMF_BPR_HOT_THRESHOLD")) h->hot_threshold = std::max(1, atoi(e5));

