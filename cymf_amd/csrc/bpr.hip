@@ -839,8 +839,9 @@ int run_one_step(cymf_bpr *h) {
         // adaptive optimizers carry per-row state whose read-modify-write is not atomic: 4x stricter
         const int64_t rpi = (int64_t)h->rows_per_inflight * (h->opt == CYMF_OPT_SGD ? 1 : h->adaptive_rpi_factor);
         const bool narrow = h->K > 128 || h->opt == CYMF_OPT_ADAM;
-        const int pf_w = narrow ? 4 : (h->step_pf > 100 ? 16 : 8);                       // lead of the user-row ring
-        const int pf_j = narrow ? 4 : (h->step_pf > 10 ? h->step_pf % 10 : h->step_pf);  // lead of the negative-row ring
+        const bool sgd = h->opt == CYMF_OPT_SGD;   // only the SGD instantiations use asymmetric leads (launch_step_pf)
+        const int pf_w = narrow ? 4 : (sgd && h->step_pf > 100 ? 16 : 8);                          // lead of the user-row ring
+        const int pf_j = narrow ? 4 : (sgd && h->step_pf > 10 ? h->step_pf % 10 : 8);              // lead of the negative-row ring
         const int64_t by_rows = std::max<int64_t>(1, std::min<int64_t>(h->I / (rpi * pf_j), h->U / (rpi * pf_w)));
         waves = std::max<int64_t>(1, std::min(waves, by_rows));
         // delta-sum exchange of a run shared by c = waves * f_max wavefronts contracts by (1 - lr*wd)^32 per wave and
