@@ -430,11 +430,13 @@ __global__ void delta_kernel(const float *__restrict__ H, const float *__restric
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) delta[i] = H[i] - snap[i];
 }
-__global__ void apply_delta_kernel(float *__restrict__ H, float *__restrict__ snap, const float *__restrict__ delta, int64_t n) {
+// scale[row]: the sequentialisation factor of that item for this step (see build_delta_scales)
+__global__ void apply_delta_kernel(float *__restrict__ H, float *__restrict__ snap, const float *__restrict__ delta,
+                                   const float *__restrict__ scale, int K, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        const float v = snap[i] + delta[i];
+        const float v = snap[i] + scale[i / K] * delta[i];
         H[i] = v;
         snap[i] = v;
     }
@@ -578,6 +580,7 @@ struct cymf_bpr {
     // multi-GPU
     cymf_comm *comm = nullptr;
     DevBuf<float> d_snap, d_delta;
+    DevBuf<float> d_delta_scale;        // [steps_per_epoch][I] sequentialisation factors of the summed deltas
 
     // profiling of the dominant kernel
     bool profiling = false;
@@ -591,6 +594,7 @@ namespace cymf {
 int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s);   // comm.hip
 int comm_world(cymf_comm *c);
 }
+
 
 namespace {
 
@@ -884,7 +888,8 @@ int run_one_step(cymf_bpr *h) {
         hipLaunchKernelGGL(delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_delta.p, n);
         CYMF_HIP(hipGetLastError());
         CYMF_TRY(comm_allreduce_sum_f32(h->comm, h->d_delta.p, n, h->stream));
-        hipLaunchKernelGGL(apply_delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_delta.p, n);
+        hipLaunchKernelGGL(apply_delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_delta.p,
+                           h->d_delta_scale.p + (size_t)s * h->I, h->K, n);
         CYMF_HIP(hipGetLastError());
     }
     h->step_cursor++;
@@ -903,6 +908,48 @@ int collect_skips(cymf_bpr *h) {   // after a stream sync: performed comes from 
     CYMF_HIP(hipStreamSynchronize(h->stream));
     h->performed = (int64_t)p;
     h->skipped = h->slots_done - h->performed;
+    return 0;
+}
+
+// Multi-GPU: every rank trains its replica of H for one step and the ranks' deltas are summed.  A plain
+// sum is only right while an item's row moves little within the step; a popular item's replica runs
+// through n/N updates per rank, each contracting it by (1 - lr*wd) towards a local equilibrium, and N
+// such deltas summed overshoot by up to N (gain -(N-1) per step: divergence, reproduced on the CPU in
+// tests/test_dist_gloo.py).  Modelling a rank's step on row i as the affine map h -> a h + b with
+// a = (1 - lr*wd')^(n_i/N), composing the N maps sequentially instead of adding them gives
+//     h_new = snap + s_i * sum_r delta_r,   s_i = (1 - a^N) / (N (1 - a))
+// (s -> 1 for rarely touched rows = plain sum; s -> 1/N for hot rows = average of the replicas).
+// n_i = positives of item i in the step over all ranks (all-reduced once here) + its expected share
+// of the uniform negatives; wd' = 2 wd leaves room for the curvature of the data term.
+int build_delta_scales(cymf_bpr *h, const std::vector<int32_t> &slot_item) {
+    const int32_t S = h->steps_per_epoch;
+    const int world = comm_world(h->comm);
+    std::vector<float> cnt((size_t)S * h->I, 0.0f);
+    for (int32_t s = 0; s < S; ++s)
+        for (int64_t t = h->step_off[s]; t < h->step_off[s + 1]; ++t) cnt[(size_t)s * h->I + slot_item[(size_t)t]] += 1.0f;
+    std::vector<float> slots((size_t)S, 0.0f);
+    for (int32_t s = 0; s < S; ++s) slots[s] = (float)(h->step_off[s + 1] - h->step_off[s]);
+    {   // global counts: exact in float32 below 2^24 per item and step
+        DevBuf<float> d;
+        CYMF_TRY(d.upload(cnt.data(), cnt.size(), h->stream));
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+        CYMF_TRY(comm_allreduce_sum_f32(h->comm, d.p, (int64_t)cnt.size(), h->stream));
+        CYMF_HIP(hipMemcpyAsync(cnt.data(), d.p, cnt.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        DevBuf<float> d2;
+        CYMF_TRY(d2.upload(slots.data(), slots.size(), h->stream));
+        CYMF_TRY(comm_allreduce_sum_f32(h->comm, d2.p, (int64_t)slots.size(), h->stream));
+        CYMF_HIP(hipMemcpyAsync(slots.data(), d2.p, slots.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+    }
+    const double base = 1.0 - std::min(0.5, 2.0 * h->lr * h->wd);
+    for (int32_t s = 0; s < S; ++s)
+        for (int32_t i = 0; i < h->I; ++i) {
+            const double n_i = (double)cnt[(size_t)s * h->I + i] + (double)slots[s] / (double)h->I;
+            const double a = std::pow(base, n_i / world);
+            cnt[(size_t)s * h->I + i] = (float)(a < 1.0 - 1e-12 ? (1.0 - std::pow(a, world)) / (world * (1.0 - a)) : 1.0);
+        }
+    CYMF_TRY(h->d_delta_scale.upload(cnt.data(), cnt.size(), h->stream));
+    CYMF_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
 
@@ -947,6 +994,7 @@ int build_throughput_layout(cymf_bpr *h) {
     CYMF_TRY(h->d_slot_user.upload(su.data(), su.size(), h->stream));
     CYMF_TRY(h->d_slot_item.upload(si.data(), si.size(), h->stream));
     if (h->item_aligned && h->opt != CYMF_OPT_SGD) h->h_slot_item = si;
+    if (h->comm) CYMF_TRY(build_delta_scales(h, si));
     h->wave_ranges_for = -1;
     CYMF_TRY(h->d_slot_pos.upload(sp.data(), sp.size(), h->stream));
     CYMF_TRY(h->d_slot_local.upload(sl.data(), sl.size(), h->stream));
@@ -1222,7 +1270,7 @@ extern "C" int cymf_bpr_attach_comm(cymf_bpr *h, cymf_comm *c) {
     if (!h || !c) return fail(CYMF_ERR_INVALID, "cymf_bpr_attach_comm: bad arguments");
     if (h->mode != CYMF_MODE_THROUGHPUT) return fail(CYMF_ERR_UNSUPPORTED, "a communicator needs throughput mode");
     if (h->opt != CYMF_OPT_SGD) return fail(CYMF_ERR_UNSUPPORTED, "multi-GPU item-delta exchange is built for sgd only");
-    if (h->have_params) return fail(CYMF_ERR_INVALID, "cymf_bpr_attach_comm must precede cymf_bpr_upload");
+    if (h->have_params || h->have_data) return fail(CYMF_ERR_INVALID, "cymf_bpr_attach_comm must precede cymf_bpr_set_data and cymf_bpr_upload");
     h->comm = c;
     return 0;
 }

@@ -30,8 +30,10 @@ def _problem():
     return X, r[perm].astype(np.int32), c[perm].astype(np.int32)
 
 
-def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce):
-    """One process's part: rank_shards = list of (rank, shard) this process emulates."""
+def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce, world=None, lr=0.05, wd=0.01, corrected=True):
+    """One process's part: rank_shards = list of (rank, shard) this process emulates.  The ranks' deltas
+    are combined as the library does: H = snapshot + s_i * sum of deltas with the sequentialisation
+    factors of cymf_amd.dist.delta_scale (host mirror of build_delta_scales in csrc/bpr.hip)."""
     import oracle
     from cymf_amd import dist
     U, I = X.shape
@@ -42,8 +44,14 @@ def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce
     for rank, shard in rank_shards:
         W, H = W0.copy(), H0.copy()
         u_l, p_l, gpos = dist.shard_triplets(users, positives, shard)
-        state[rank] = dict(W=W, H=H, snap=H.copy(), m=oracle.Bpr(W, H, "sgd", 0.05, 0.01), u=u_l, p=p_l, g=gpos,
+        state[rank] = dict(W=W, H=H, snap=H.copy(), m=oracle.Bpr(W, H, "sgd", lr, wd), u=u_l, p=p_l, g=gpos,
                            step=dist.step_of(gpos, S, N), seen=np.zeros(N, dtype=np.int64))
+    world = world or len(rank_shards)
+    step_glob = dist.step_of(np.arange(N), S, N)      # the global windows are known to every rank
+    scales = []
+    for s in range(S):
+        n_i = np.bincount(positives[step_glob == s], minlength=I) + (step_glob == s).sum() / I
+        scales.append(dist.delta_scale(n_i, world, lr, wd) if corrected else np.ones(I))
     for ep in range(epochs):
         draws = oracle.uniform_stream(1234, I, N, skip=ep * N).astype(np.int32)
         for s in range(S):
@@ -55,7 +63,7 @@ def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce
                 st["m"].apply(st["u"][sel][ok], st["p"][sel][ok], neg[ok])
                 st["seen"][st["g"][sel]] += 1
             deltas = {rank: st["H"] - st["snap"] for rank, st in state.items()}
-            total = allreduce(deltas)                                         # sum over ALL ranks of the job
+            total = allreduce(deltas) * scales[s][:, None]                    # sum over ALL ranks of the job, damped
             for rank, st in state.items():
                 st["H"][:] = st["snap"] + total
                 st["snap"][:] = st["H"]
@@ -78,7 +86,7 @@ def _worker(rank, world, port, out_dir):
         td.all_reduce(t)
         return t.numpy()
 
-    st = _run_rank_schedule([(rank, shards[rank])], X, users, positives, 16, 5, 2, allreduce)[rank]
+    st = _run_rank_schedule([(rank, shards[rank])], X, users, positives, 16, 5, 2, allreduce, world=world)[rank]
     seen = torch.from_numpy(st["seen"].copy())
     td.all_reduce(seen)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), W=st["W"], H=st["H"], seen=seen.numpy(), shard=np.array(shards[rank]))
@@ -123,3 +131,29 @@ def test_step_windows_partition_the_global_order():
     assert st.min() == 0 and st.max() == S - 1 and (np.diff(st) >= 0).all()
     counts = np.bincount(st, minlength=S)
     assert counts.sum() == N and counts.max() - counts.min() <= 1
+
+
+def test_delta_sum_needs_the_sequentialisation_factor():
+    """Why the summed deltas are damped per item: with a strongly contracting step (many updates of a
+    popular item per rank and step) a plain sum of N replicas' deltas has gain -(N-1) and diverges;
+    with the factor (1 - a^N) / (N (1 - a)) the N-rank schedule stays as calm as the 1-rank one."""
+    from cymf_amd import dist, synthetic
+    X = synthetic.implicit_matrix(1200, 200, 30000, 78)
+    rs = np.random.RandomState(6)
+    r, c = X.nonzero()
+    perm = rs.permutation(len(r))
+    users, positives = r[perm].astype(np.int32), c[perm].astype(np.int32)
+    lr, wd = 0.05, 0.2
+    out = {}
+    for world, corrected in ((1, True), (6, False), (6, True)):
+        shards = dist.user_shards(X.indptr, world)
+        st = _run_rank_schedule(list(enumerate(shards)), X, users, positives, 8, 1, 7, lambda d: sum(d.values()),
+                                world=world, lr=lr, wd=wd, corrected=corrected)
+        out[(world, corrected)] = float(np.abs(st[0]["H"]).max())
+    assert out[(6, False)] > 50 * out[(1, True)]          # plain sum: blows up
+    assert out[(6, True)] < 3 * out[(1, True)] + 1e-3     # damped sum: bounded like the single rank
+    # and in the weakly contracting regime the factor is ~1 (plain sum): nothing is slowed down
+    s = dist.delta_scale(np.array([0.0, 5.0, 50.0]), 8, 0.05, 0.01)
+    assert s[0] == 1.0 and s[1] > 0.99 and 0.95 < s[2] < 1.0
+    assert dist.delta_scale(np.array([1e6]), 8, 0.05, 0.01)[0] == pytest.approx(1 / 8, rel=1e-6)
+    assert (dist.delta_scale(np.array([0.0, 10.0, 1e6]), 1, 0.05, 0.01) == 1.0).all()
