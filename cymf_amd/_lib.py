@@ -76,6 +76,11 @@ def lib():
         "cymf_wmf_half_sweep": ([vp, ci], ci),
         "cymf_wmf_epochs": ([vp, i32], ci),
         "cymf_wmf_destroy": ([vp], ci),
+        "cymf_eval_create": ([pp, i32, i32, vp, vp, vp, vp, vp, i32, ci], ci),
+        "cymf_eval_num_users": ([vp, vp], ci),
+        "cymf_eval_negatives": ([vp, u32, i32, vp, vp, vp], ci),
+        "cymf_eval_run": ([vp, vp, vp, i32, u32, i32, vp, i32, vp, ci, vp], ci),
+        "cymf_eval_destroy": ([vp], ci),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)   # AttributeError here = the .so does not export the header's symbol

@@ -168,6 +168,30 @@ int cymf_wmf_half_sweep(cymf_wmf *h, int side);
 int cymf_wmf_epochs(cymf_wmf *h, int32_t n_epochs);
 int cymf_wmf_destroy(cymf_wmf *h);
 
+/* ---------------------------------------------------------------- Evaluator
+ * replaces the per-user loop of Evaluator.evaluate, cymf/evaluator.pyx:57-139: candidate
+ * sampling from UniformGenerator(0, I, seed) with redraw on known positives (:80-88), the
+ * scores np.dot(H[items], W[user]) and their descending order (:90), and the metrics of
+ * cymf/metrics.pyx:24-147 (DCG, Recall, MAP @k and their IPS variants, which index the
+ * propensities by candidate position: evaluator.pyx:92).
+ *   X (test) and user_positives (test + train, sorted unique indices) are CSR patterns.
+ *   cymf_eval_run: out[(m * nk + ki) * U + user], m = 0 DCG, 1 Recall, 2 MAP; users without
+ *   held-out items get 0 (they still count in the caller's mean, :134-136).
+ *   discounts[r] = 1 for r = 0, log2(r + 1) after (cymf/metrics.pyx:36-41), max(k) entries. */
+typedef struct cymf_eval cymf_eval;
+int cymf_eval_create(cymf_eval **out, int32_t U, int32_t I, const int32_t *test_indptr,
+                     const int32_t *test_indices, const int32_t *all_indptr,
+                     const int32_t *all_indices, const double *propensity, int32_t n_propensity,
+                     int device);
+int cymf_eval_num_users(cymf_eval *h, int32_t *n_eval);
+/* the sampled negatives, [n_eval][num_negatives] in user order, and the evaluated users */
+int cymf_eval_negatives(cymf_eval *h, uint32_t seed, int32_t num_negatives, int32_t *users_out,
+                        int32_t *neg_out, int64_t *draws_used);
+int cymf_eval_run(cymf_eval *h, const double *W, const double *H, int32_t K, uint32_t seed,
+                  int32_t num_negatives, const int32_t *ks, int32_t nk, const double *discounts,
+                  int unbiased, double *out);
+int cymf_eval_destroy(cymf_eval *h);
+
 #ifdef __cplusplus
 }
 #endif
