@@ -305,37 +305,44 @@ __global__ __launch_bounds__(WMF_THREADS) void wmf_row_mfma_kernel(int32_t rows,
 // Register-resident solve.  The in-LDS Cholesky above spends its time in barriers and LDS latency
 // (two workgroup barriers and a read-modify-write of the trailing triangle per column): measured
 // 24 us of CU time per K=64 row on C4, 5-10x the Gramian that precedes it.  Here one lane owns one ROW of the
-// system, in registers: K <= 64 -> one wavefront per row (no barrier at all), K <= 128 -> two.
-//   column step c : every lane publishes its (not yet scaled) A[j][c] and b_j through a double-buffered
-//                   LDS column; the pivot d = A[c][c] and the other rows' entries come back as
-//                   wave-uniform (broadcast) ds_read_b128; L[j][c] = A[j][c]/sqrt(d) stays in place and
-//                       A[j][q] -= (A[j][c]/d) * A[q][c]   for q > c     (one FMA per element)
-//                   which also carries the forward substitution on b along (z_c = b_c/sqrt(d)).
-//   back substitution: x_c = (z_c - sum_{r>c} L[r][c] x_r) / L[c][c], the sum as a DPP wave reduction.
+// (full, symmetric) system, in registers: K <= 64 -> one wavefront per row (no barrier at all), K <= 128 -> two.
+// Gauss-Jordan without pivoting (the matrix is SPD, lambda > 0 on the diagonal):
+//   column step c : every lane publishes its A[j][c] through a double-buffered LDS column; the pivot
+//                   d = A[c][c] comes back by v_readlane (one wave) or LDS, the pivot ROW A[c][q] is, by the symmetry of
+//                   the not yet eliminated block, the published COLUMN and comes back as wave-uniform
+//                   (broadcast) ds_read_b128:
+//                       A[j][q] -= (A[j][c]/d) * A[c][q],  b_j -= (A[j][c]/d) * b_c   for every row j != c, q > c
+//                   -- one FMA per element, the same arithmetic for rows below AND above the pivot, so there is
+//                   no triangle to skip, no square root and no back substitution: x_j = b_j / pivot_j at the end.
 // Everything is unrolled over c and q so that the row is addressed by static register numbers.
-// Lanes above the diagonal compute garbage that is never read (their A[j][q], j < q, is dead).
 template <int NW>
 __device__ __forceinline__ void group_sync() {
     if constexpr (NW > 1) __syncthreads();
     else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave: LDS executes in order; only stop compiler motion
 }
 
-__device__ __forceinline__ float rsqrt_nr(float d) {   // v_rsq_f32 + one Newton step
-    float y = __frsqrt_rn(d);
-    return y * (1.5f - 0.5f * d * y * y);
+__device__ __forceinline__ float rcp_nr(float d) {   // v_rcp_f32 + one Newton step
+    const float y = __frcp_rn(d);
+    return y * (2.0f - d * y);
 }
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
 // column step C (template recursion instead of a loop: the row must be addressed by static register numbers,
-// and a `#pragma unroll` the optimizer declines turns a[] into v_movrel indexing)
+// and a `#pragma unroll` the optimizer declines turns a[] into v_movrel indexing).  The row is kept as K/2
+// register pairs and updated with v_pk_fma_f32 (two FMAs per instruction): half the issue slots and, as
+// important at K=128, half the code -- the unrolled elimination is straight-line code that every wave streams
+// through once per row, and it has to stay near the 64 KB instruction cache.  Pairs are updated whole: an entry
+// left of the pivot column is dead, so touching it is harmless.
 template <int K, int NW, int C>
-__device__ __forceinline__ void chol_column(float (&a)[K], float &bj, float &myinv, int j, float *colbuf, float *bbuf) {
+__device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &mypiv, int j, float *colbuf, float *bbuf) {
     using f4 = __attribute__((ext_vector_type(4))) float;
     constexpr int KP = 64 * NW;   // one slot per lane: idle lanes (j >= K) publish into slots nobody reads, no branch
     float *cb = colbuf + (C & 1) * KP;
-    const float raw = a[C];
+    const float raw = a[C / 2][C & 1];
     cb[j] = raw;
     float d, bc;
-    if constexpr (NW == 1) {      // the pivot row is a lane of this wave: no LDS round trip in front of the rsqrt chain
+    if constexpr (NW == 1) {      // the pivot row is a lane of this wave: no LDS round trip in front of the reciprocal
         d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw), C));
         bc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bj), C));
         group_sync<NW>();
@@ -346,52 +353,34 @@ __device__ __forceinline__ void chol_column(float (&a)[K], float &bj, float &myi
         d = cb[C];
         bc = bb[C];
     }
-    const float inv = rsqrt_nr(d);
-    const float l = raw * inv;
-    const float t = l * inv;
-    a[C] = l;
-    myinv = j == C ? inv : myinv;
-    bj = j > C ? bj - t * bc : (j == C ? bc * inv : bj);
+    const float rd = rcp_nr(d);
+    const float nt = j == C ? 0.0f : -(raw * rd);
+    mypiv = j == C ? rd : mypiv;
+    bj += nt * bc;
+    const f32x2 nt2 = {nt, nt};
     const f4 *cb4 = reinterpret_cast<const f4 *>(cb);
 #pragma unroll
     for (int g = (C + 1) / 4; g < K / 4; ++g) {
         const f4 v = cb4[g];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (4 * g + e > C) {
-                a[4 * g + e] -= t * v[e];
+        for (int h = 0; h < 2; ++h)
+            if (4 * g + 2 * h + 1 > C) {
+                const f32x2 vh = {v[2 * h], v[2 * h + 1]};
+                a[2 * g + h] = __builtin_elementwise_fma(nt2, vh, a[2 * g + h]);
                 // the update is pinned to its column: left alone, the compiler sinks the FMAs of far columns
                 // to their first use and keeps every broadcast value alive for them (K=32 took 390 VGPRs)
-                asm volatile("" : "+v"(a[4 * g + e]));
+                asm volatile("" : "+v"(a[2 * g + h]));
             }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (C + 1 < K) chol_column<K, NW, C + 1>(a, bj, myinv, j, colbuf, bbuf);
-}
-
-template <int K, int NW, int C>
-__device__ __forceinline__ void chol_back(const float (&a)[K], float bj, float myinv, float &x, int j, float *red) {
-    const float tt = (j > C && j < K) ? a[C] * x : 0.0f;
-    float s = wave_sum(tt);
-    if constexpr (NW > 1) {
-        float *rb = red + (C & 1) * NW;
-        if ((threadIdx.x & 63) == 0) rb[threadIdx.x >> 6] = s;
-        __syncthreads();
-        s = 0.0f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s += rb[w];
-    }
-    x = j == C ? (bj - s) * myinv : x;      // 1/L[c][c] kept from the forward pass
-    if constexpr (C > 0) chol_back<K, NW, C - 1>(a, bj, myinv, x, j, red);
+    if constexpr (C + 1 < K) gj_column<K, NW, C + 1>(a, bj, mypiv, j, colbuf, bbuf);
 }
 
 template <int K, int NW>
-__device__ __forceinline__ float chol_solve_reg(float (&a)[K], float bj, int j, float *colbuf, float *bbuf, float *red) {
-    float myinv = 0.0f;
-    chol_column<K, NW, 0>(a, bj, myinv, j, colbuf, bbuf);
-    float x = 0.0f;
-    chol_back<K, NW, K - 1>(a, bj, myinv, x, j, red);
-    return x;
+__device__ __forceinline__ float solve_reg(f32x2 (&a)[K / 2], float bj, int j, float *colbuf, float *bbuf) {
+    float mypiv = 0.0f;   // 1 / pivot of this lane's row
+    gj_column<K, NW, 0>(a, bj, mypiv, j, colbuf, bbuf);
+    return bj * mypiv;
 }
 
 // t-th pair (m <= n) of the row-major upper triangle of a T32 x T32 tile grid
@@ -407,7 +396,7 @@ constexpr size_t wmf_reg_smem() { return sizeof(float) * ((size_t)NW * WMF_STAGE
 // row out of the NW staged tiles.  Template recursion over rounds and tiles: the tile coordinates of a staged
 // tile must be compile-time constants, they select the registers a[32 n + e] the values are added to.
 template <int T32, int NW, int W, int Q>
-__device__ __forceinline__ void stage_take(float (&a)[32 * T32], const float *stage, int jb, int jl) {
+__device__ __forceinline__ void stage_take(f32x2 (&a)[16 * T32], const float *stage, int jb, int jl) {
     constexpr int NT = T32 * (T32 + 1) / 2;
     constexpr int t = W + NW * Q;
     if constexpr (t < NT) {
@@ -416,18 +405,18 @@ __device__ __forceinline__ void stage_take(float (&a)[32 * T32], const float *st
         // branch-free (a branch around updates of a register subset costs a copy of the whole row at the join)
         const float hit_m = jb == m ? 1.0f : 0.0f;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) a[32 * n + e] += hit_m * st[jl * 33 + e];
+        for (int e = 0; e < 32; ++e) a[16 * n + e / 2][e & 1] += hit_m * st[jl * 33 + e];
         if constexpr (m != n) {             // the mirrored block reads the tile's transpose
             const float hit_n = jb == n ? 1.0f : 0.0f;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) a[32 * m + e] += hit_n * st[e * 33 + jl];
+            for (int e = 0; e < 32; ++e) a[16 * m + e / 2][e & 1] += hit_n * st[e * 33 + jl];
         }
     }
     if constexpr (W + 1 < NW) stage_take<T32, NW, W + 1, Q>(a, stage, jb, jl);
 }
 
 template <int T32, int NW, int Q, int TPW>
-__device__ __forceinline__ void stage_rounds(float (&a)[32 * T32], const f32x16 (&acc)[TPW], const float (&bsum)[TPW],
+__device__ __forceinline__ void stage_rounds(f32x2 (&a)[16 * T32], const f32x16 (&acc)[TPW], const float (&bsum)[TPW],
                                              const int (&tm)[TPW], const int (&tn)[TPW], float *stage, float *bvec,
                                              float weight, int jb, int jl, int wave, int li, int lh) {
     constexpr int NT = T32 * (T32 + 1) / 2;
@@ -455,7 +444,7 @@ template <int T32, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(int32_t rows, const int32_t *__restrict__ indptr,
                                                              const int32_t *__restrict__ indices, float *__restrict__ X,
                                                              const float *__restrict__ Y, const float *__restrict__ A0,
-                                                             float weight, int32_t long_threshold) {
+                                                             float weight, int32_t long_threshold, int probe) {
     constexpr int K = 32 * T32;
     constexpr int NT = T32 * (T32 + 1) / 2;
     constexpr int TPW = (NT + NW - 1) / NW;
@@ -464,12 +453,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
     float *colbuf = stage + ((NW * WMF_STAGE + 3) & ~3);   // [2][64 NW], 16-byte aligned
     float *bbuf = colbuf + 2 * 64 * NW;                    // [2][64 NW]
     float *bvec = bbuf + 2 * 64 * NW;                      // [K]
-    float *red = bvec + K;                                 // [2][NW]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = NW == 1 ? 0 : tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
 
     for (int32_t i = blockIdx.x; i < rows; i += gridDim.x) {
-        const int32_t p0 = indptr[i], p1 = indptr[i + 1];
+        const int32_t p0 = indptr[i];
+        int32_t p1 = indptr[i + 1];
         int j = tid;
         asm volatile("" : "+v"(j));   // opaque per row: keeps the 2K lane comparisons of the solve from being hoisted into (spilled) SGPR pairs
         if (p0 == p1) {                                        // wmf.pyx:154-156
@@ -477,6 +466,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
             continue;
         }
         if (long_threshold > 0 && p1 - p0 > long_threshold) continue;   // built from segments
+        if (probe == 2) p1 = p0;                                         // timing probe: no gather, no MFMA
         f32x16 acc[TPW];
         float bsum[TPW];
         int tm[TPW], tn[TPW];
@@ -489,35 +479,36 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
             tm[q] = m;
             tn[q] = m + rem;
         }
+        // 64 gathered rows per batch; each of the T32 32-column chunks of a gathered row is loaded once per
+        // step and feeds every tile that uses it (tile (m, n) multiplies chunk m by chunk n)
         for (int32_t pb = p0; pb < p1; pb += 64) {
             const int32_t myp = pb + lane;
             const int32_t myidx = myp < p1 ? indices[myp] : -1;
             const int nb = p1 - pb < 64 ? p1 - pb : 64;
             const int steps = (nb + 1) >> 1;
             for (int s0 = 0; s0 < steps; s0 += 8) {
-                float av[8][TPW], bv[8][TPW];
+                float ch[8][T32];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int32_t idx = __shfl(myidx, 2 * (s0 + u) + lh, 64);
                     const bool ok = idx >= 0;
                     const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
 #pragma unroll
-                    for (int q = 0; q < TPW; ++q) {
-                        av[u][q] = 0.0f;
-                        bv[u][q] = 0.0f;
-                        if (wave + NW * q < NT) {   // wave-uniform
-                            av[u][q] = ok ? yrow[32 * tm[q] + li] : 0.0f;
-                            bv[u][q] = ok ? yrow[32 * tn[q] + li] : 0.0f;
-                        }
-                    }
+                    for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
 #pragma unroll
                     for (int q = 0; q < TPW; ++q) {
                         if (wave + NW * q < NT) {
-                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q], bv[u][q], acc[q], 0, 0, 0);
-                            if (tm[q] == tn[q]) bsum[q] += av[u][q];
+                            float av = ch[u][0], bv = ch[u][0];
+#pragma unroll
+                            for (int m = 1; m < T32; ++m) {      // chunk select: compile-time for one wave per row
+                                av = tm[q] == m ? ch[u][m] : av;
+                                bv = tn[q] == m ? ch[u][m] : bv;
+                            }
+                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
+                            if (tm[q] == tn[q]) bsum[q] += av;
                         }
                     }
                 }
@@ -526,20 +517,20 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
         // lane j <- row j of A = A0 + (w-1) G
         const int jr = j < K ? j : 0;
         const int jb = jr >> 5, jl = jr & 31;
-        float a[K];
+        f32x2 a[K / 2];
         {
             using f4 = __attribute__((ext_vector_type(4))) float;
             const f4 *a0 = reinterpret_cast<const f4 *>(A0 + (size_t)jr * K);
 #pragma unroll
             for (int g = 0; g < K / 4; ++g) {
                 const f4 v = a0[g];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a[4 * g + e] = v[e];
+                a[2 * g] = f32x2{v[0], v[1]};
+                a[2 * g + 1] = f32x2{v[2], v[3]};
             }
         }
         stage_rounds<T32, NW, 0, TPW>(a, acc, bsum, tm, tn, stage, bvec, weight, jb, jl, wave, li, lh);
         group_sync<NW>();
-        const float x = chol_solve_reg<K, NW>(a, bvec[jr], j, colbuf, bbuf, red);
+        const float x = probe == 1 ? a[0][0] + bvec[jr] : solve_reg<K, NW>(a, bvec[jr], j, colbuf, bbuf);   // (1: timing probe, no solve)
         if (j < K) X[(int64_t)i * K + j] = x;                  // wmf.pyx:170-171
     }
 }
@@ -583,6 +574,7 @@ struct cymf_wmf {
     DevBuf<int32_t> d_indptr, d_indices, d_tindptr, d_tindices;
     bool have_data = false, have_params = false;
     bool use_mfma = true;
+    int probe = 0;           // CYMF_WMF_PROBE: 1 skips the solve, 2 the Gramian (timing only, results invalid)
     bool reg_solve = true;   // register-resident solve (wmf_row_reg_kernel); CYMF_WMF_LDS_SOLVE=1 selects the in-LDS one
     // rows with more than long_threshold entries are built from segments (MFMA path)
     int32_t long_threshold = 2048;
@@ -669,7 +661,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_>, smem_r));                                                     \
             const int grid_r = (int)std::min<int64_t>(rows, 256 * 64);                                                      \
             hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream, rows, ip,  \
-                               ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0);                        \
+                               ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe);              \
         } else {                                                                                                            \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, false>), dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, ip, \
                                ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, segs, nseg, h->d_scratch.p); \
@@ -710,6 +702,7 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     h->U = U; h->I = I; h->K = K; h->weight = weight; h->wd = weight_decay; h->dtype = dtype; h->device = device;
     const char *env = getenv("CYMF_WMF_NO_MFMA");
     h->use_mfma = !(env && env[0] == '1');
+    if (const char *e4 = getenv("CYMF_WMF_PROBE")) h->probe = atoi(e4);
     if (const char *e3 = getenv("CYMF_WMF_LDS_SOLVE")) h->reg_solve = !(e3[0] == '1');
     if (const char *e2 = getenv("CYMF_WMF_LONG")) h->long_threshold = std::max(64, atoi(e2));
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);

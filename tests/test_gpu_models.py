@@ -145,6 +145,26 @@ def test_wmf_mfma_and_generic_kernels_agree(monkeypatch):
     assert _close(out[0][0], out[1][0], 1e-5) and _close(out[0][1], out[1][1], 1e-5)
 
 
+@pytest.mark.parametrize("K", [32, 64, 96, 128])
+def test_wmf_register_and_lds_solvers_agree(K, monkeypatch):
+    """The register-resident Gauss-Jordan solve (one lane per row of the system) and the in-LDS Cholesky
+    are two routes to the same x = A^-1 b; rows of 0, 1 and > 64 entries, lanes beyond K idle (K=32, 96)."""
+    X = synthetic.implicit_matrix(500, 300, 9000, 34).tolil()
+    X[3] = 0
+    X[7] = 0
+    X[7, 11] = 1.0
+    X = X.tocsr()
+    X.eliminate_zeros()
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CYMF_WMF_LDS_SOLVE", flag)
+        m = WMF(K, 0.01, 10.0)
+        m.fit(X, num_epochs=2, verbose=False, dtype="float32")
+        out.append((m.W.copy(), m.H.copy()))
+    assert _close(out[0][0], out[1][0], 1e-4) and _close(out[0][1], out[1][1], 1e-4)   # both sit ~1e-5 from the f64 oracle at K=128
+    assert (out[0][0][3] == 0).all()
+
+
 def test_wmf_fixed_point_property():
     """Size-independent property: after a user half-sweep every non-empty row satisfies its own
     normal equations A_u w_u = b_u (checked in float64 on the host)."""
