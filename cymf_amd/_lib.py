@@ -76,6 +76,8 @@ def lib():
         "cymf_wmf_half_sweep": ([vp, ci], ci),
         "cymf_wmf_epochs": ([vp, i32], ci),
         "cymf_wmf_destroy": ([vp], ci),
+        "cymf_wmf_attach_comm": ([vp, vp], ci),
+        "cymf_wmf_row_range": ([vp, ci, vp, vp], ci),
         "cymf_eval_create": ([pp, i32, i32, vp, vp, vp, vp, vp, i32, ci], ci),
         "cymf_eval_num_users": ([vp, vp], ci),
         "cymf_eval_negatives": ([vp, u32, i32, vp, vp, vp], ci),

@@ -27,6 +27,26 @@ int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s)
 }
 
 int comm_world(cymf_comm *c) { return c ? c->world : 1; }
+int comm_rank(cymf_comm *c) { return c ? c->rank : 0; }
+
+// In-place all-gather of unequal contiguous row ranges: rank r owns rows [row_bounds[r], row_bounds[r+1]) of the
+// table at d_buf and every rank ends with all of them.  One grouped set of broadcasts (RCCL fuses the group).
+int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_t row_bytes, hipStream_t s) {
+    if (c->world == 1) return 0;
+    CYMF_NCCL(ncclGroupStart());
+    for (int r = 0; r < c->world; ++r) {
+        const int64_t n = (row_bounds[r + 1] - row_bounds[r]) * row_bytes;
+        if (n <= 0) continue;
+        char *p = static_cast<char *>(d_buf) + row_bounds[r] * row_bytes;
+        ncclResult_t rc = ncclBroadcast(p, p, (size_t)n, ncclChar, r, c->comm, s);
+        if (rc != ncclSuccess) {
+            (void)ncclGroupEnd();
+            return ::cymf::fail(CYMF_ERR_RCCL, "ncclBroadcast failed: %s", ncclGetErrorString(rc));
+        }
+    }
+    CYMF_NCCL(ncclGroupEnd());
+    return 0;
+}
 
 }  // namespace cymf
 

@@ -564,6 +564,12 @@ struct WmfStore {
     DevBuf<T> W, H, G;
 };
 
+namespace cymf {
+int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_t row_bytes, hipStream_t s);   // comm.hip
+int comm_world(cymf_comm *c);
+int comm_rank(cymf_comm *c);
+}  // namespace cymf
+
 struct cymf_wmf {
     int32_t U = 0, I = 0, K = 0;
     int dtype = 0, device = 0;
@@ -574,6 +580,11 @@ struct cymf_wmf {
     DevBuf<int32_t> d_indptr, d_indices, d_tindptr, d_tindices;
     bool have_data = false, have_params = false;
     bool use_mfma = true;
+    // multi-GPU: rows of each side are cut into one contiguous range per rank, balanced by
+    // entries + a constant per solve; a rank solves its rows and the ranges are all-gathered after the sweep
+    cymf_comm *comm = nullptr;
+    int shard_rank = 0, shard_world = 1;   // from comm; CYMF_WMF_FAKE_SHARD="r/w" (tests) sets them without a communicator: no gather
+    std::vector<int64_t> bounds[2];   // [world + 1] row boundaries per side (empty = single GPU)
     int probe = 0;           // CYMF_WMF_PROBE: 1 skips the solve, 2 the Gramian (timing only, results invalid)
     bool reg_solve = true;   // register-resident solve (wmf_row_reg_kernel); CYMF_WMF_LDS_SOLVE=1 selects the in-LDS one
     // rows with more than long_threshold entries are built from segments (MFMA path)
@@ -603,6 +614,19 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
     const T *Y = side == 0 ? st.H.p : st.W.p;
     const int32_t *ip = side == 0 ? h->d_indptr.p : h->d_tindptr.p;
     const int32_t *ix = side == 0 ? h->d_indices.p : h->d_tindices.p;
+    // this rank's rows [lo, hi): the whole-row kernels get the CSR and the output offset by lo (indptr values are
+    // absolute positions in indices); the long-row lists were already cut to the range in set_data
+    int32_t lo = 0, hi = rows;
+    if (!h->bounds[side].empty()) {
+        lo = (int32_t)h->bounds[side][h->shard_rank];
+        hi = (int32_t)h->bounds[side][h->shard_rank + 1];
+    }
+    T *const X_all = X;
+    X += (size_t)lo * K;
+    ip += lo;
+    const int32_t rows_all = rows;
+    (void)rows_all;
+    const int32_t my_rows = hi - lo;
     CYMF_TRY(st.G.alloc((size_t)K * K + K));   // K*K Gramian (+ K: the column sums the MFMA path also produces)
     CYMF_TRY(st.G.zero(h->stream));
     const bool mfma_ok = sizeof(T) == 4 && h->use_mfma && K % 32 == 0 && K <= 128;
@@ -635,7 +659,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
     }
     hipLaunchKernelGGL(wmf_add_diag_kernel<T>, dim3((K + 63) / 64), dim3(64), 0, h->stream, st.G.p, K, (T)h->wd);
     CYMF_HIP(hipGetLastError());
-    const int grid = (int)std::min<int64_t>(rows, 256 * 16);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(my_rows, 256 * 16));
     bool mfma = false;
     if constexpr (sizeof(T) == 4) {
         if (h->use_mfma && K % 32 == 0 && K <= 128) {
@@ -643,6 +667,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             size_t smem = sizeof(float) * ((size_t)K * (K + 1) + 2 * K);
             const float *Yf = reinterpret_cast<const float *>(Y);
             float *Xf = reinterpret_cast<float *>(X);
+            float *Xf_all = reinterpret_cast<float *>(X_all);
             const float *Gf = reinterpret_cast<const float *>(st.G.p);
             const int32_t nseg = h->n_segs[side], nlong = h->n_long[side];
             const WmfSeg *segs = h->d_segs[side].p;
@@ -653,17 +678,18 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, false>, smem));                                                        \
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, true>, smem));                                                         \
         if (nseg > 0)   /* segments of the long rows first: the longest work starts earliest */                             \
-            hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, rows, \
+            hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, my_rows, \
                                ip, ix, Xf, Yf, Gf, (float)h->weight, h->long_threshold, segs, nseg, h->d_scratch.p);        \
-        if (h->reg_solve) {                                                                                                 \
+        if (my_rows <= 0) {                                                                                                 \
+        } else if (h->reg_solve) {                                                                                          \
             constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                        \
             const size_t smem_r = wmf_reg_smem<T32_, NW_>();                                                                \
             CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_>, smem_r));                                                     \
-            const int grid_r = (int)std::min<int64_t>(rows, 256 * 64);                                                      \
-            hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream, rows, ip,  \
+            const int grid_r = (int)std::min<int64_t>(my_rows, 256 * 64);                                                   \
+            hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream, my_rows, ip, \
                                ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe);              \
         } else {                                                                                                            \
-            hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, false>), dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, ip, \
+            hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, false>), dim3(grid), dim3(WMF_THREADS), smem, h->stream, my_rows, ip, \
                                ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, segs, nseg, h->d_scratch.p); \
         }                                                                                                                   \
     } while (0)
@@ -676,7 +702,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
 #undef WMF_LAUNCH_
             if (nlong > 0) {
                 CYMF_TRY(allow_lds(wmf_long_finish_kernel, smem));
-                hipLaunchKernelGGL(wmf_long_finish_kernel, dim3(nlong), dim3(WMF_THREADS), smem, h->stream, K, h->d_long_rows[side].p, Xf, Gf,
+                hipLaunchKernelGGL(wmf_long_finish_kernel, dim3(nlong), dim3(WMF_THREADS), smem, h->stream, K, h->d_long_rows[side].p, Xf_all, Gf,
                                    h->d_scratch.p, (float)h->weight);
             }
         }
@@ -684,9 +710,12 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
     if (!mfma) {
         size_t smem = sizeof(T) * ((size_t)K * (K + 1) + 2 * K + (size_t)WMF_TILE * K);
         CYMF_TRY(allow_lds(wmf_row_kernel<T>, smem));
-        hipLaunchKernelGGL(wmf_row_kernel<T>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, rows, K, ip, ix, X, Y, st.G.p, (T)h->weight);
+        if (my_rows > 0)
+            hipLaunchKernelGGL(wmf_row_kernel<T>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, my_rows, K, ip, ix, X, Y, st.G.p, (T)h->weight);
     }
     CYMF_HIP(hipGetLastError());
+    if (h->comm && !h->bounds[side].empty())   // every rank ends the half-sweep with the whole updated table
+        CYMF_TRY(comm_allgatherv(h->comm, X_all, h->bounds[side].data(), (int64_t)K * (int64_t)sizeof(T), h->stream));
     return 0;
 }
 
@@ -703,11 +732,32 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     const char *env = getenv("CYMF_WMF_NO_MFMA");
     h->use_mfma = !(env && env[0] == '1');
     if (const char *e4 = getenv("CYMF_WMF_PROBE")) h->probe = atoi(e4);
+    if (const char *e5 = getenv("CYMF_WMF_FAKE_SHARD")) {
+        int r = 0, w = 1;
+        if (sscanf(e5, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) { h->shard_rank = r; h->shard_world = w; }
+    }
     if (const char *e3 = getenv("CYMF_WMF_LDS_SOLVE")) h->reg_solve = !(e3[0] == '1');
     if (const char *e2 = getenv("CYMF_WMF_LONG")) h->long_threshold = std::max(64, atoi(e2));
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     *out = h;
+    return 0;
+}
+
+extern "C" int cymf_wmf_attach_comm(cymf_wmf *h, cymf_comm *c) {
+    if (!h || !c) return fail(CYMF_ERR_INVALID, "cymf_wmf_attach_comm: bad arguments");
+    if (h->have_data) return fail(CYMF_ERR_INVALID, "cymf_wmf_attach_comm must precede cymf_wmf_set_data");
+    h->comm = c;
+    h->shard_rank = comm_rank(c);
+    h->shard_world = comm_world(c);
+    return 0;
+}
+
+extern "C" int cymf_wmf_row_range(cymf_wmf *h, int side, int32_t *lo, int32_t *hi) {
+    if (!h || (side != 0 && side != 1) || !lo || !hi || !h->have_data) return fail(CYMF_ERR_INVALID, "cymf_wmf_row_range: bad arguments / no data");
+    *lo = 0;
+    *hi = side == 0 ? h->U : h->I;
+    if (!h->bounds[side].empty()) { *lo = (int32_t)h->bounds[side][h->shard_rank]; *hi = (int32_t)h->bounds[side][h->shard_rank + 1]; }
     return 0;
 }
 
@@ -737,9 +787,25 @@ extern "C" int cymf_wmf_set_data(cymf_wmf *h, const int32_t *indptr, const int32
     for (int side = 0; side < 2; ++side) {
         const int32_t *ip = side == 0 ? indptr : t_indptr;
         const int32_t rows = side == 0 ? h->U : h->I;
+        int32_t r_lo = 0, r_hi = rows;
+        h->bounds[side].clear();
+        if (h->shard_world > 1) {   // contiguous row ranges of equal cost (entries + a constant per solve), the same on every rank
+            const int world = h->shard_world;
+            const int64_t per_solve = std::max(16, h->K / 2);
+            const int64_t total = (int64_t)ip[rows] + per_solve * rows;
+            h->bounds[side].assign((size_t)world + 1, rows);
+            h->bounds[side][0] = 0;
+            int next = 1;
+            for (int32_t r = 0; r < rows && next < world; ++r) {
+                const int64_t before = (int64_t)ip[r] + per_solve * r;
+                while (next < world && before >= total * next / world) h->bounds[side][next++] = r;
+            }
+            r_lo = (int32_t)h->bounds[side][h->shard_rank];
+            r_hi = (int32_t)h->bounds[side][h->shard_rank + 1];
+        }
         std::vector<WmfSeg> segs;
         std::vector<int32_t> longs;
-        for (int32_t r = 0; r < rows; ++r) {
+        for (int32_t r = r_lo; r < r_hi; ++r) {
             const int32_t n = ip[r + 1] - ip[r];
             if (n <= h->long_threshold) continue;
             const int32_t slot = (int32_t)longs.size();

@@ -20,9 +20,11 @@ class WMF(object):
         self.H = None
 
     def fit(self, X, num_epochs=5, num_threads=1, valid_evaluator=None, early_stopping=False, verbose=True,
-            *, dtype="float32", device=0):
+            *, dtype="float32", device=0, comm=None):
         """cymf/wmf.pyx:59-93.  ALS is deterministic and thread-count independent in the reference,
-        so num_threads is accepted and ignored; only the pattern of X is used (wmf.pyx:111)."""
+        so num_threads is accepted and ignored; only the pattern of X is used (wmf.pyx:111).
+        comm (a dist.Comm, one process per GPU): the rows of every half-sweep are split over the ranks and
+        all-gathered; every rank passes the same X and ends with the same full W and H."""
         X = _host.coerce_csr(X)
         self.valid_evaluator = valid_evaluator
         self.valid_dcg = -np.inf
@@ -33,7 +35,8 @@ class WMF(object):
         U, I = X.shape
         _host.init_factors(self, U, I, self.num_components)
         Xt = X.T.tocsr()                                          # wmf.pyx:112
-        trainer = WmfTrainer(U, I, self.num_components, self.weight, self.weight_decay, dtype=dtype, device=device)
+        trainer = WmfTrainer(U, I, self.num_components, self.weight, self.weight_decay, dtype=dtype,
+                             device=device if comm is None else comm.device, comm=comm)
         try:
             trainer.set_data(X.indptr, X.indices, Xt.indptr, Xt.indices)
             trainer.upload(self.W, self.H)
@@ -60,12 +63,15 @@ class WMF(object):
 class WmfTrainer:
     """Object wrapper of the cymf_wmf_* C ABI."""
 
-    def __init__(self, U, I, K, weight=10.0, weight_decay=0.01, dtype="float32", device=0):
+    def __init__(self, U, I, K, weight=10.0, weight_decay=0.01, dtype="float32", device=0, comm=None):
         self.L = _lib.lib()
         self.U, self.I, self.K = int(U), int(I), int(K)
         self.h = C.c_void_p()
         _lib.check(self.L.cymf_wmf_create(C.byref(self.h), self.U, self.I, self.K, weight, weight_decay,
                                           _lib.DTYPE_IDS[dtype], device))
+        self.comm = comm          # keeps the communicator alive as long as the trainer
+        if comm is not None:
+            _lib.check(self.L.cymf_wmf_attach_comm(self.h, comm.h))
 
     def set_data(self, indptr, indices, t_indptr, t_indices):
         a, b, c, d = _lib.i32c(indptr), _lib.i32c(indices), _lib.i32c(t_indptr), _lib.i32c(t_indices)
@@ -81,6 +87,12 @@ class WmfTrainer:
 
     def download(self, W, H):
         _lib.check(self.L.cymf_wmf_download(self.h, _lib.ptr(W), _lib.ptr(H)))
+
+    def row_range(self, side):
+        """Rows [lo, hi) of side 0 (users) / 1 (items) this rank solves."""
+        lo, hi = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.L.cymf_wmf_row_range(self.h, int(side), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     def half_sweep(self, side):
         _lib.check(self.L.cymf_wmf_half_sweep(self.h, int(side)))

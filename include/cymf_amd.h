@@ -167,6 +167,13 @@ int cymf_wmf_download(cymf_wmf *h, double *W, double *H);
 int cymf_wmf_half_sweep(cymf_wmf *h, int side);
 int cymf_wmf_epochs(cymf_wmf *h, int32_t n_epochs);
 int cymf_wmf_destroy(cymf_wmf *h);
+/* Multi-GPU (no counterpart in the reference; its prange over rows, cymf/wmf.pyx:150, is the same independence):
+ * the rows of each side are cut into one contiguous range per rank, a rank solves its range and the updated
+ * table is all-gathered after every half-sweep, so every rank holds the full W and H -- the results do not
+ * depend on the number of ranks.  Every rank passes the full CSR to cymf_wmf_set_data; call before it. */
+int cymf_wmf_attach_comm(cymf_wmf *h, cymf_comm *c);
+/* rows [lo, hi) of side 0 (users) / 1 (items) this handle solves (the whole side without a communicator) */
+int cymf_wmf_row_range(cymf_wmf *h, int side, int32_t *lo, int32_t *hi);
 
 /* ---------------------------------------------------------------- Evaluator
  * replaces the per-user loop of Evaluator.evaluate, cymf/evaluator.pyx:57-139: candidate

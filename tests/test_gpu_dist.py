@@ -72,3 +72,15 @@ def test_user_shard_consumes_its_draws_of_the_global_stream():
         assert np.array_equal(W[other], W0[other].astype(np.float32).astype(np.float64))   # foreign user rows untouched
         t.close()
     assert (seen == 1).all()
+
+
+def test_wmf_with_world1_communicator_equals_plain_fit():
+    """cymf_wmf_attach_comm at world size 1: one range covering every row, the gather is the identity."""
+    from cymf_amd import WMF
+    comm = dist.Comm(0, 1, 0, dist.Comm.unique_id())
+    X = synthetic.implicit_matrix(600, 500, 20000, 63)
+    a, b = WMF(64, 0.01, 10.0), WMF(64, 0.01, 10.0)
+    a.fit(X, num_epochs=2, verbose=False)
+    b.fit(X, num_epochs=2, verbose=False, comm=comm)
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H)
+    comm.close()

@@ -165,6 +165,50 @@ def test_wmf_register_and_lds_solvers_agree(K, monkeypatch):
     assert (out[0][0][3] == 0).all()
 
 
+@pytest.mark.parametrize("K,dtype", [(64, "float32"), (128, "float32"), (20, "float64")])
+def test_wmf_row_shards_reproduce_the_single_gpu_sweep(K, dtype, monkeypatch):
+    """Multi-GPU row sharding without the collective: three handles act as ranks 0..2 of 3 (test hook
+    CYMF_WMF_FAKE_SHARD), each solves its contiguous row range of a half-sweep; the ranges tile the side and
+    their union equals the unsharded sweep up to the order noise of the atomically summed YtY (a row's result
+    does not depend on who solves it).  Long rows (> threshold, built from segments) included."""
+    monkeypatch.setenv("CYMF_WMF_LONG", "64")
+    X = synthetic.implicit_matrix(900, 400, 30000, 35)
+    Xt = X.T.tocsr()
+    W0, H0 = oracle.reference_init(900, 400, K)
+
+    def sweep(side, shard):
+        if shard:
+            monkeypatch.setenv("CYMF_WMF_FAKE_SHARD", shard)
+        else:
+            monkeypatch.delenv("CYMF_WMF_FAKE_SHARD", raising=False)
+        t = WmfTrainer(900, 400, K, 10.0, 0.01, dtype=dtype)
+        t.set_data(X.indptr, X.indices, Xt.indptr, Xt.indices)
+        t.upload(W0, H0)
+        t.half_sweep(side)
+        W, H = np.empty_like(W0), np.empty_like(H0)
+        t.download(W, H)
+        rng = t.row_range(side)
+        t.close()
+        return (W if side == 0 else H), rng
+
+    for side, rows in ((0, 900), (1, 400)):
+        full, rng = sweep(side, None)
+        assert rng == (0, rows)
+        init = W0 if side == 0 else H0
+        got = np.full_like(full, np.nan)
+        edges = []
+        for r in range(3):
+            part, (lo, hi) = sweep(side, f"{r}/3")
+            edges.append((lo, hi))
+            got[lo:hi] = part[lo:hi]
+            outside = np.ones(rows, dtype=bool)
+            outside[lo:hi] = False
+            assert np.array_equal(part[outside], init[outside].astype(dtype).astype(np.float64))   # other ranks' rows untouched
+        assert edges[0][0] == 0 and edges[-1][1] == rows and all(edges[k][1] == edges[k + 1][0] for k in range(2))
+        assert min(hi - lo for lo, hi in edges) > rows // 6                              # balanced, nobody idle
+        assert _close(got, full, 1e-6 if dtype == "float32" else 1e-12)   # (YtY is summed with atomics: order noise only)
+
+
 def test_wmf_fixed_point_property():
     """Size-independent property: after a user half-sweep every non-empty row satisfies its own
     normal equations A_u w_u = b_u (checked in float64 on the host)."""
