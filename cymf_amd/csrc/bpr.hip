@@ -920,7 +920,8 @@ int collect_skips(cymf_bpr *h) {   // after a stream sync: performed comes from 
 //     h_new = snap + s_i * sum_r delta_r,   s_i = (1 - a^N) / (N (1 - a))
 // (s -> 1 for rarely touched rows = plain sum; s -> 1/N for hot rows = average of the replicas).
 // n_i = positives of item i in the step over all ranks (all-reduced once here) + its expected share
-// of the uniform negatives; wd' = 2 wd leaves room for the curvature of the data term.
+// of the uniform negatives; wd' = 2 wd leaves room for the curvature of the data term.  The optimizer state
+// (AdaGrad accumulators, Adam moments) of the item rows stays private to the rank, like W: only H is exchanged.
 int build_delta_scales(cymf_bpr *h, const std::vector<int32_t> &slot_item) {
     const int32_t S = h->steps_per_epoch;
     const int world = comm_world(h->comm);
@@ -941,7 +942,14 @@ int build_delta_scales(cymf_bpr *h, const std::vector<int32_t> &slot_item) {
         CYMF_HIP(hipMemcpyAsync(slots.data(), d2.p, slots.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         CYMF_HIP(hipStreamSynchronize(h->stream));
     }
-    const double base = 1.0 - std::min(0.5, 2.0 * h->lr * h->wd);
+    // per-touch contraction of a replica towards its local equilibrium, by optimizer (all validated on the CPU
+    // emulation, tests/test_dist_gloo.py): SGD 2 lr wd (the isotropic part; the data term acts along one w per
+    // touch); AdaGrad never steps further than SGD (acc >= 1) but its early steps are data-dominated: lr/5;
+    // Adam moves every element by about lr per touch whatever the gradient: 5 lr.
+    double rho = 2.0 * h->lr * h->wd;
+    if (h->opt == CYMF_OPT_ADAGRAD) rho = std::max(rho, 0.2 * h->lr);
+    if (h->opt == CYMF_OPT_ADAM) rho = 5.0 * h->lr;
+    const double base = 1.0 - std::min(0.5, rho);
     for (int32_t s = 0; s < S; ++s)
         for (int32_t i = 0; i < h->I; ++i) {
             const double n_i = (double)cnt[(size_t)s * h->I + i] + (double)slots[s] / (double)h->I;
@@ -1269,7 +1277,6 @@ extern "C" int cymf_bpr_last_negatives(cymf_bpr *h, int32_t *out, int64_t n) {
 extern "C" int cymf_bpr_attach_comm(cymf_bpr *h, cymf_comm *c) {
     if (!h || !c) return fail(CYMF_ERR_INVALID, "cymf_bpr_attach_comm: bad arguments");
     if (h->mode != CYMF_MODE_THROUGHPUT) return fail(CYMF_ERR_UNSUPPORTED, "a communicator needs throughput mode");
-    if (h->opt != CYMF_OPT_SGD) return fail(CYMF_ERR_UNSUPPORTED, "multi-GPU item-delta exchange is built for sgd only");
     if (h->have_params || h->have_data) return fail(CYMF_ERR_INVALID, "cymf_bpr_attach_comm must precede cymf_bpr_set_data and cymf_bpr_upload");
     h->comm = c;
     return 0;

@@ -34,6 +34,7 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 int use_device(int device);   // validates + hipSetDevice; CYMF_ERR_NO_DEVICE if none
+int default_memtype();        // CYMF_DEFAULT_MEMTYPE (0 coarse, 1 fine-grained = default, 2 uncached), read once
 
 // ------------------------------------------------------------------ device memory
 template <typename T>
@@ -49,15 +50,24 @@ struct DevBuf {
         p = nullptr;
         n = 0;
     }
-    // fine == true: fine-grained device memory (not cached by the per-XCD L2s, coherent between
-    // the 8 XCDs inside one kernel); used for tables that many wavefronts update concurrently.
-    int fine = 0;   // 0 default (coarse-grained), 1 hipDeviceMallocFinegrained, 2 hipDeviceMallocUncached
+    // Memory type.  -1 = the library default (default_memtype(): fine-grained), 0 = coarse-grained (hipMalloc),
+    // 1 = hipDeviceMallocFinegrained, 2 = hipDeviceMallocUncached.
+    //   * Fine-grained is the default because coarse-grained buffers handed from one kernel to the next were
+    //     observed STALE on some MI355X boxes: a consumer kernel on another XCD read lines its L2 had kept from an
+    //     earlier life of the same address (a freed buffer, the previous epoch's draws) although producer and
+    //     consumer were ordered on one stream -- intermittent, per box, gone with fine-grained or uncached
+    //     hand-off buffers (tests/test_gpu_dist.py history).  Fine-grained memory is still cached
+    //     inside a kernel; it costs nothing measurable on the streaming and gather paths here.
+    //   * Uncached (2) is for tables that wavefronts of ONE kernel update concurrently from all 8 XCDs
+    //     (HOGWILD): the per-XCD L2s are not coherent with each other inside a kernel for any cached type.
+    int fine = -1;
     int alloc(size_t count) {
         if (count == n && p) return 0;
         release();
         if (count == 0) return 0;
-        hipError_t e = fine ? hipExtMallocWithFlags((void **)&p, count * sizeof(T), fine == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained)
-                            : hipMalloc((void **)&p, count * sizeof(T));
+        const int mt = fine < 0 ? default_memtype() : fine;
+        hipError_t e = mt ? hipExtMallocWithFlags((void **)&p, count * sizeof(T), mt == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained)
+                          : hipMalloc((void **)&p, count * sizeof(T));
         if (e != hipSuccess) {
             p = nullptr;
             return fail(CYMF_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));

@@ -1,6 +1,8 @@
 // core.hip -- error state, device selection, library info.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace cymf {
 
 static thread_local std::string g_err;
@@ -32,6 +34,15 @@ static int device_count_quiet() {
         return 0;
     }
     return n;
+}
+
+int default_memtype() {
+    static const int mt = [] {
+        const char *e = getenv("CYMF_DEFAULT_MEMTYPE");
+        const int v = e ? atoi(e) : 1;
+        return v < 0 || v > 2 ? 1 : v;
+    }();
+    return mt;
 }
 
 int use_device(int device) {

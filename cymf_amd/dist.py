@@ -44,10 +44,20 @@ def step_of(global_pos, steps_per_epoch, n_global):
     return (np.asarray(global_pos, dtype=np.int64) * int(steps_per_epoch)) // max(int(n_global), 1)
 
 
-def delta_scale(n_i, world, lr, wd):
+def delta_rho(optimizer, lr, wd):
+    """Per-touch contraction assumed for a replica of an item row (host mirror of build_delta_scales, csrc/bpr.hip)."""
+    rho = 2.0 * lr * wd
+    if optimizer == "adagrad":
+        rho = max(rho, 0.2 * lr)
+    elif optimizer == "adam":
+        rho = 5.0 * lr
+    return min(0.5, rho)
+
+
+def delta_scale(n_i, world, lr, wd, optimizer="sgd"):
     """Sequentialisation factor of the summed item-factor deltas (host mirror of build_delta_scales in
     csrc/bpr.hip): n_i = updates of the item in the step over all ranks."""
-    base = 1.0 - min(0.5, 2.0 * lr * wd)
+    base = 1.0 - delta_rho(optimizer, lr, wd)
     a = base ** (np.asarray(n_i, dtype=np.float64) / world)
     small = a >= 1.0 - 1e-12
     return np.where(small, 1.0, (1.0 - a ** world) / (world * np.where(small, 1.0, 1.0 - a)))

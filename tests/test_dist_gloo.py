@@ -30,7 +30,8 @@ def _problem():
     return X, r[perm].astype(np.int32), c[perm].astype(np.int32)
 
 
-def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce, world=None, lr=0.05, wd=0.01, corrected=True):
+def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce, world=None, lr=0.05, wd=0.01, corrected=True,
+                       optimizer="sgd"):
     """One process's part: rank_shards = list of (rank, shard) this process emulates.  The ranks' deltas
     are combined as the library does: H = snapshot + s_i * sum of deltas with the sequentialisation
     factors of cymf_amd.dist.delta_scale (host mirror of build_delta_scales in csrc/bpr.hip)."""
@@ -44,14 +45,14 @@ def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce
     for rank, shard in rank_shards:
         W, H = W0.copy(), H0.copy()
         u_l, p_l, gpos = dist.shard_triplets(users, positives, shard)
-        state[rank] = dict(W=W, H=H, snap=H.copy(), m=oracle.Bpr(W, H, "sgd", lr, wd), u=u_l, p=p_l, g=gpos,
+        state[rank] = dict(W=W, H=H, snap=H.copy(), m=oracle.Bpr(W, H, optimizer, lr, wd), u=u_l, p=p_l, g=gpos,
                            step=dist.step_of(gpos, S, N), seen=np.zeros(N, dtype=np.int64))
     world = world or len(rank_shards)
     step_glob = dist.step_of(np.arange(N), S, N)      # the global windows are known to every rank
     scales = []
     for s in range(S):
         n_i = np.bincount(positives[step_glob == s], minlength=I) + (step_glob == s).sum() / I
-        scales.append(dist.delta_scale(n_i, world, lr, wd) if corrected else np.ones(I))
+        scales.append(dist.delta_scale(n_i, world, lr, wd, optimizer) if corrected else np.ones(I))
     for ep in range(epochs):
         draws = oracle.uniform_stream(1234, I, N, skip=ep * N).astype(np.int32)
         for s in range(S):
@@ -60,7 +61,8 @@ def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce
                 sel = sel[np.argsort(st["p"][sel], kind="stable")]            # item-bucketed, as the kernel walks them
                 neg = draws[st["g"][sel]]
                 ok = ~dense[st["u"][sel], neg]
-                st["m"].apply(st["u"][sel][ok], st["p"][sel][ok], neg[ok])
+                st["loss"] = st.get("loss", 0.0) * (ep == st.get("ep", -1)) + st["m"].apply(st["u"][sel][ok], st["p"][sel][ok], neg[ok])
+                st["ep"] = ep
                 st["seen"][st["g"][sel]] += 1
             deltas = {rank: st["H"] - st["snap"] for rank, st in state.items()}
             total = allreduce(deltas) * scales[s][:, None]                    # sum over ALL ranks of the job, damped
@@ -157,3 +159,27 @@ def test_delta_sum_needs_the_sequentialisation_factor():
     assert s[0] == 1.0 and s[1] > 0.99 and 0.95 < s[2] < 1.0
     assert dist.delta_scale(np.array([1e6]), 8, 0.05, 0.01)[0] == pytest.approx(1 / 8, rel=1e-6)
     assert (dist.delta_scale(np.array([0.0, 10.0, 1e6]), 1, 0.05, 0.01) == 1.0).all()
+
+
+@pytest.mark.parametrize("optimizer,lr", [("adam", 0.05), ("adagrad", 0.5)])
+def test_adaptive_optimizers_shard_with_private_state(optimizer, lr):
+    """Adam / AdaGrad across ranks: the moments / accumulators of the item rows stay private to the rank (like W),
+    only H is exchanged, damped with the optimizer's own per-touch contraction (dist.delta_rho).  At an aggressive
+    learning rate the plain sum of six replicas' deltas diverges; the damped sum trains like a single rank."""
+    from cymf_amd import dist, synthetic
+    X = synthetic.implicit_matrix(1200, 200, 30000, 78)
+    rs = np.random.RandomState(6)
+    r, c = X.nonzero()
+    perm = rs.permutation(len(r))
+    users, positives = r[perm].astype(np.int32), c[perm].astype(np.int32)
+    out = {}
+    for world, corrected in ((1, True), (6, False), (6, True)):
+        shards = dist.user_shards(X.indptr, world)
+        st = _run_rank_schedule(list(enumerate(shards)), X, users, positives, 8, 1, 6, lambda d: sum(d.values()),
+                                world=world, lr=lr, wd=0.01, corrected=corrected, optimizer=optimizer)
+        out[(world, corrected)] = (float(np.abs(st[0]["H"]).max()), sum(s["loss"] for s in st.values()))
+    assert out[(6, False)][0] > 3 * out[(1, True)][0]                 # plain sum: item factors run away
+    assert out[(6, True)][0] < 2.5 * out[(1, True)][0]                # damped: same scale as the single rank
+    assert out[(6, True)][1] < 0.7 * out[(6, False)][1]               # and a far lower last-epoch loss
+    assert dist.delta_rho("sgd", 0.05, 0.01) == pytest.approx(0.001) and dist.delta_rho("adam", 0.001, 0.01) == pytest.approx(0.005)
+    assert dist.delta_rho("adagrad", 0.05, 0.01) == pytest.approx(0.01) and dist.delta_rho("adam", 1.0, 0.01) == 0.5

@@ -40,8 +40,17 @@ def test_rccl_world1_allreduce_and_trainer_exchange():
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-2)
     assert out[0][3] == out[1][3]
     assert abs(np.linalg.norm(out[0][2]) / np.linalg.norm(out[1][2]) - 1) < 1e-2
+    # Adam with a communicator: optimizer state private to the rank, identity exchange at world size 1
+    out = []
+    for c in (None, comm):
+        t = BprTrainer(4000, 3000, 64, "adam", 0.01, 0.01, mode="throughput", steps_per_epoch=5, comm=c)
+        t.set_data(users, pos, indptr, indices)
+        t.upload(W0, H0)
+        out.append(t.epochs(3))
+        t.close()
+    np.testing.assert_allclose(out[0], out[1], rtol=2e-2)
     with pytest.raises(Exception):
-        BprTrainer(10, 10, 8, "adam", mode="throughput", comm=comm)     # sgd only in round 1
+        BprTrainer(10, 10, 8, "sgd", mode="exact", comm=comm)           # the sequential order is single-GPU by definition
     comm.close()
 
 
