@@ -119,7 +119,8 @@ int cymf_comm_create(cymf_comm **out, const char id[CYMF_UNIQUE_ID_BYTES], int r
 int cymf_comm_destroy(cymf_comm *c);
 /* host buffer all-reduce (op 0 = sum, 1 = max): rendezvous/timing helper and test hook */
 int cymf_comm_allreduce_f32(cymf_comm *c, float *host_inout, int64_t n, int op);
-/* call before cymf_bpr_set_data (the per-step item counts are all-reduced there) */
+/* call before cymf_bpr_set_data (the per-step item counts are all-reduced there).  Throughput mode, any
+ * optimizer: only H is exchanged, optimizer state of the item rows stays private to the rank. */
 int cymf_bpr_attach_comm(cymf_bpr *h, cymf_comm *c);
 
 /* ---------------------------------------------------------------- RelMF
