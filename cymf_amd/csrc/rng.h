@@ -21,8 +21,8 @@ struct RngState {
 class DeviceRng {
   public:
     ~DeviceRng();
-    // range in [1, 2^32-1]; parallel = use the chunked generator (falls back to serial when the
-    // Lemire rejection rate of `range` is too high for its per-chunk rejection list)
+    // range in [1, 2^32-1]; parallel = use the chunked generator (the one-workgroup walker still serves
+    // ranges whose Lemire rejection rate exceeds ~8 %: the per-chunk rejection list would outgrow 2 MB)
     int init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel = false);
     // Discards n_skip draws, then writes the next n draws to d_out[0..n) (device pointer), in
     // stream order on `s`.  Asynchronous; the stream position is settled lazily (finalize).
@@ -38,6 +38,7 @@ class DeviceRng {
     DevBuf<RngState> st_;
     uint32_t range_ = 0, thr_ = 0;
     bool parallel_ = false;
+    int64_t rej_cap_ = 0;               // rejection-list entries per chunk
     // parallel mode
     uint64_t raw_pos_ = 0;              // next unconsumed raw word of the stream
     DevBuf<uint32_t> poly_, states_, tmp_, counts_, rej_, rej_cnt_;

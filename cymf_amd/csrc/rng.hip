@@ -193,7 +193,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void mt_jump_kernel(const uint32_t *_
     }
 }
 
-constexpr int REJ_CAP = 8192;   // recorded rejection offsets per chunk
+constexpr int REJ_CAP_MIN = 8192;   // recorded rejection offsets per chunk (at least; sized from the range's rejection rate)
 
 // Workgroup q generates chunk (c0 + q) of the raw stream from its start state and writes the
 // accepted words (Lemire) compacted to tmp[q*J ...]; words before skip0 belong to an earlier call
@@ -201,7 +201,8 @@ constexpr int REJ_CAP = 8192;   // recorded rejection offsets per chunk
 __global__ __launch_bounds__(RNG_THREADS) void rng_chunk_kernel(const uint32_t *__restrict__ states, uint32_t skip0,
                                                                uint32_t range, uint32_t thr,
                                                                uint32_t *__restrict__ tmp, uint32_t *__restrict__ counts,
-                                                               uint32_t *__restrict__ rej, uint32_t *__restrict__ rej_cnt) {
+                                                               uint32_t *__restrict__ rej, uint32_t *__restrict__ rej_cnt,
+                                                               uint32_t rej_cap) {
     __shared__ uint32_t buf[2][MT_N];
     __shared__ int s_wcnt[RNG_THREADS / 64];
     __shared__ uint32_t s_nrej;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(RNG_THREADS) void rng_chunk_kernel(const uint32_t *
     const int q = blockIdx.x;
     const uint32_t first = q == 0 ? skip0 : 0u;
     uint32_t *__restrict__ out = tmp + (size_t)q * MT_JUMP_WORDS;
-    uint32_t *__restrict__ myrej = rej + (size_t)q * REJ_CAP;
+    uint32_t *__restrict__ myrej = rej + (size_t)q * rej_cap;
     for (int k = tid; k < MT_N; k += RNG_THREADS) buf[0][k] = states[(size_t)q * MT_N + k];
     if (tid == 0) s_nrej = 0;
     int cur = 0;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(RNG_THREADS) void rng_chunk_kernel(const uint32_t *
             special |= have && !ok[r];
             if (live && !acc) {
                 const uint32_t slot = atomicAdd(&s_nrej, 1u);
-                if (slot < REJ_CAP) myrej[slot] = off0 + w;
+                if (slot < rej_cap) myrej[slot] = off0 + w;
             }
         }
         if (!__syncthreads_or(special)) {
@@ -327,8 +328,11 @@ int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel)
     hipLaunchKernelGGL(rng_seed_kernel, dim3(1), dim3(64), 0, s, st_.p, seed);
     CYMF_HIP(hipGetLastError());
     // the per-chunk rejection list must hold the expected rejections with a wide margin
+    // (a range like U*I = 1.6e8 of RelMF rejects 3 % of the words: 130 k per chunk)
     const double rej_per_chunk = (double)thr_ / 4294967296.0 * (double)MT_JUMP_WORDS;
-    parallel_ = parallel && rej_per_chunk * 8.0 + 64.0 < (double)REJ_CAP;
+    rej_cap_ = REJ_CAP_MIN;
+    while ((double)rej_cap_ < rej_per_chunk * 1.5 + 4096.0) rej_cap_ *= 2;
+    parallel_ = parallel && rej_cap_ <= (1 << 19);   // beyond ~8 % rejections the one-workgroup walker serves (2 MB of list per chunk)
     if (parallel_) {
         CYMF_TRY(poly_.upload(MT_JUMP_POLY, MT_N, s));
         states_cap_ = 64;
@@ -372,7 +376,7 @@ int DeviceRng::finalize() {
     int64_t prefix = 0;
     for (int64_t q = 0; q < pend_.n_chunks; ++q) {
         const int64_t cnt = pend_.h_counts[q];
-        if (pend_.h_rej_cnt[q] > (uint32_t)REJ_CAP)
+        if (pend_.h_rej_cnt[q] > (uint32_t)rej_cap_)
             return fail(CYMF_ERR_UNSUPPORTED, "index stream: %u rejections in one chunk exceed the parallel generator's list",
                         pend_.h_rej_cnt[q]);
         if (prefix + cnt >= pend_.n_total) {
@@ -380,7 +384,7 @@ int DeviceRng::finalize() {
             // r (+ skip0 in chunk 0) plus the rejected words at or before it
             const int64_t r = pend_.n_total - 1 - prefix;
             uint64_t pos = (uint64_t)r + (q == 0 ? pend_.skip0 : 0);
-            uint32_t *lst = pend_.h_rej + (size_t)q * REJ_CAP;
+            uint32_t *lst = pend_.h_rej + (size_t)q * rej_cap_;
             const uint32_t nr = pend_.h_rej_cnt[q];
             std::sort(lst, lst + nr);
             for (uint32_t i = 0; i < nr && (uint64_t)lst[i] <= pos; ++i) ++pos;
@@ -410,13 +414,13 @@ int DeviceRng::generate_parallel(int64_t n_total, int64_t n_skip, uint32_t *d_ou
         pend_.cap_chunks = n_chunks * 2;
         CYMF_HIP(hipHostMalloc((void **)&pend_.h_counts, (size_t)pend_.cap_chunks * sizeof(uint32_t)));
         CYMF_HIP(hipHostMalloc((void **)&pend_.h_rej_cnt, (size_t)pend_.cap_chunks * sizeof(uint32_t)));
-        CYMF_HIP(hipHostMalloc((void **)&pend_.h_rej, (size_t)pend_.cap_chunks * REJ_CAP * sizeof(uint32_t)));
+        CYMF_HIP(hipHostMalloc((void **)&pend_.h_rej, (size_t)pend_.cap_chunks * rej_cap_ * sizeof(uint32_t)));
         CYMF_TRY(counts_.alloc((size_t)pend_.cap_chunks));
         CYMF_TRY(rej_cnt_.alloc((size_t)pend_.cap_chunks));
-        CYMF_TRY(rej_.alloc((size_t)pend_.cap_chunks * REJ_CAP));
+        CYMF_TRY(rej_.alloc((size_t)pend_.cap_chunks * rej_cap_));
     }
     hipLaunchKernelGGL(rng_chunk_kernel, dim3((unsigned)n_chunks), dim3(RNG_THREADS), 0, s, states_.p + (size_t)c0 * MT_N,
-                       (uint32_t)skip0, range_, thr_, tmp_.p, counts_.p, rej_.p, rej_cnt_.p);
+                       (uint32_t)skip0, range_, thr_, tmp_.p, counts_.p, rej_.p, rej_cnt_.p, (uint32_t)rej_cap_);
     CYMF_HIP(hipGetLastError());
     if (d_out && n_total > n_skip) {
         hipLaunchKernelGGL(rng_gather_kernel, dim3(64, (unsigned)n_chunks), dim3(256), 0, s, tmp_.p, counts_.p, (int)n_chunks,
@@ -425,7 +429,7 @@ int DeviceRng::generate_parallel(int64_t n_total, int64_t n_skip, uint32_t *d_ou
     }
     CYMF_HIP(hipMemcpyAsync(pend_.h_counts, counts_.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     CYMF_HIP(hipMemcpyAsync(pend_.h_rej_cnt, rej_cnt_.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    CYMF_HIP(hipMemcpyAsync(pend_.h_rej, rej_.p, (size_t)n_chunks * REJ_CAP * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CYMF_HIP(hipMemcpyAsync(pend_.h_rej, rej_.p, (size_t)n_chunks * rej_cap_ * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     CYMF_HIP(hipEventRecord(pend_.done, s));
     pend_.active = true;
     pend_.c0 = c0; pend_.n_chunks = n_chunks; pend_.n_total = n_total; pend_.skip0 = skip0;

@@ -386,6 +386,230 @@ __global__ void unpack2_kernel(const float2 *__restrict__ in, float *__restrict_
     for (; i < n; i += stride) { a[i] = in[i].x; b[i] = in[i].y; }
 }
 
+// ---------------------------------------------------------------- RelMF throughput path (f32)
+// The epoch's U*I cells are redrawn every epoch (relmf.pyx:142-146), so the bucketing that the BPR and
+// GloVe step kernels get once from the host is done on the device per epoch: a counting sort of the
+// cells by user (histogram, scan, scatter of the item ids).  One wavefront then owns whole users: W[u]
+// (and its optimizer state) stays in registers for the user's ~I draws, the row of X it needs (I floats)
+// stays in cache, and the item rows come through a ring of loads issued PF slots ahead.  Every item is
+// equally popular here (uniform cells): with a few thousand wavefronts in flight each item row has
+// several holders at any time, so a slot ADDS its delta of H[i] (float atomics) instead of storing the
+// row back; the optimizer state of H[i] is stored plainly (a lost update there perturbs a running
+// average, a delta-sum of moments is unstable: see bpr.hip).
+__global__ void relmf_hist_kernel(const uint32_t *__restrict__ cells, int64_t n, uint32_t I, uint32_t *__restrict__ cnt) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n; t += stride) atomicAdd(cnt + cells[t] / I, 1u);
+}
+
+// exclusive scan of U counts -> off[U+1] (int64) and the scatter cursors; one workgroup
+__global__ __launch_bounds__(1024) void relmf_scan_kernel(const uint32_t *__restrict__ cnt, int32_t U, int64_t *__restrict__ off,
+                                                         unsigned long long *__restrict__ cursor) {
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int32_t per = (U + 1023) / 1024;
+    const int32_t b = tid * per, e = b + per < U ? b + per : U;
+    int64_t sum = 0;
+    for (int32_t u = b; u < e; ++u) sum += cnt[u];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int q = 0; q < 1024; ++q) { const int64_t v = part[q]; part[q] = run; run += v; }
+        off[U] = run;
+    }
+    __syncthreads();
+    int64_t run = part[tid];
+    for (int32_t u = b; u < e; ++u) { off[u] = run; cursor[u] = (unsigned long long)run; run += cnt[u]; }
+}
+
+__global__ void relmf_scatter_kernel(const uint32_t *__restrict__ cells, int64_t n, uint32_t I,
+                                     unsigned long long *__restrict__ cursor, int32_t *__restrict__ items) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < n; t += stride) {
+        const uint32_t c = cells[t], u = c / I;
+        items[atomicAdd(cursor + u, 1ull)] = (int32_t)(c - u * I);
+    }
+}
+
+// Bucketing with workgroup-private counters in LDS (U <= RELMF_LDS_USERS): a workgroup takes a contiguous segment
+// of < 65536 cells, counts it into packed 16-bit LDS counters (two users per word), and touches the global
+// counters once per (workgroup, user) instead of once per cell -- the global-atomic version spends 18 ms of a
+// 160 M-cell epoch on its 320 M contended atomics.  The scatter reserves the workgroup's range of every user
+// it holds with one global atomic and ranks its own cells with returning LDS atomics.
+constexpr int RELMF_LDS_USERS = 24576;        // 4 U (bases) + 2 U (counters) bytes of LDS <= 144 KB
+constexpr int RELMF_SEG = 49152;              // cells per workgroup (< 65536: a 16-bit counter cannot overflow)
+
+__global__ __launch_bounds__(1024) void relmf_hist_lds_kernel(const uint32_t *__restrict__ cells, int64_t n, uint32_t I, int32_t U,
+                                                             uint32_t *__restrict__ cnt) {
+    extern __shared__ uint32_t sm[];           // [ceil(U/2)] packed counters
+    const int tid = threadIdx.x;
+    const int words = (U + 1) >> 1;
+    for (int k = tid; k < words; k += 1024) sm[k] = 0u;
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * RELMF_SEG, e = b + RELMF_SEG < n ? b + RELMF_SEG : n;
+    for (int64_t t = b + tid; t < e; t += 1024) {
+        const uint32_t u = cells[t] / I;
+        atomicAdd(sm + (u >> 1), 1u << (16 * (u & 1)));
+    }
+    __syncthreads();
+    for (int u = tid; u < U; u += 1024) {
+        const uint32_t c = (sm[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+        if (c) atomicAdd(cnt + u, c);
+    }
+}
+
+__global__ __launch_bounds__(1024) void relmf_scatter_lds_kernel(const uint32_t *__restrict__ cells, int64_t n, uint32_t I, int32_t U,
+                                                                unsigned long long *__restrict__ cursor,
+                                                                int32_t *__restrict__ items) {
+    extern __shared__ uint32_t sm[];           // [U] bases, then [ceil(U/2)] packed counters
+    uint32_t *base = sm;
+    uint32_t *cnt2 = sm + U;
+    const int tid = threadIdx.x;
+    const int words = (U + 1) >> 1;
+    for (int k = tid; k < words; k += 1024) cnt2[k] = 0u;
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * RELMF_SEG, e = b + RELMF_SEG < n ? b + RELMF_SEG : n;
+    for (int64_t t = b + tid; t < e; t += 1024) {
+        const uint32_t u = cells[t] / I;
+        atomicAdd(cnt2 + (u >> 1), 1u << (16 * (u & 1)));
+    }
+    __syncthreads();
+    for (int u = tid; u < U; u += 1024) {
+        const uint32_t c = (cnt2[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+        base[u] = c ? (uint32_t)atomicAdd(cursor + u, (unsigned long long)c) : 0u;   // (N < 2^32: the stream's range)
+    }
+    __syncthreads();
+    for (int k = tid; k < words; k += 1024) cnt2[k] = 0u;
+    __syncthreads();
+    for (int64_t t = b + tid; t < e; t += 1024) {
+        const uint32_t c = cells[t], u = c / I;
+        const uint32_t sh = 16 * (u & 1);
+        const uint32_t r = (atomicAdd(cnt2 + (u >> 1), 1u << sh) >> sh) & 0xffffu;
+        items[(int64_t)base[u] + r] = (int32_t)(c - u * I);
+    }
+}
+
+struct RelStepDev {
+    float *W, *H, *W0, *W1, *H0, *H1;
+    const float *X, *prop;
+    int K;
+    int64_t I;
+    float wd, clip;
+    OptParams<float> opt;
+};
+
+template <int R, bool PACKED, int OPT, int PF>
+__global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int64_t *__restrict__ off,
+                                                        const int32_t *__restrict__ items, int32_t U,
+                                                        int32_t users_per_wave, double *__restrict__ loss_acc) {
+    using RowT = Row<float, R, PACKED>;
+    constexpr int NS = opt_num_states(OPT);
+    constexpr int NSA = NS ? NS : 1;
+    constexpr int RING = 2 * PF;
+    static_assert(64 % RING == 0, "ring must divide the chunk");
+    const int lane = lane_id();
+    const int K = d.K;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t u_begin = wave * users_per_wave;
+    const int64_t u_end = u_begin + users_per_wave < U ? u_begin + users_per_wave : U;
+    float *const Ws[2] = {d.W0, d.W1};
+    float *const Hs[2] = {d.H0, d.H1};
+    float loss_sum = 0.0f;
+    for (int64_t u = u_begin; u < u_end; ++u) {
+        const int64_t s_begin = off[u], s_end = off[u + 1];
+        if (s_begin >= s_end) continue;
+        const int64_t c_end = (s_end - s_begin + 63) >> 6;
+        const float *xrow = d.X + u * d.I;
+        RowT w, sw[NSA];
+        w.load(d.W + u * K, K, lane);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sw[q].load(Ws[q] + u * K, K, lane);
+        auto load_meta = [&](int64_t c) -> int32_t {
+            const int64_t my = s_begin + (c << 6) + lane;
+            return (c < c_end && my < s_end) ? items[my] : -1;
+        };
+        int32_t it_c = load_meta(0), it_n = load_meta(1);
+        RowT hq[RING], shq[RING][NSA];
+        float xq[RING], pq[RING];
+        auto issue = [&](int e, int32_t i) {
+            const int64_t oi = (int64_t)(i < 0 ? 0 : i) * K;
+            hq[e].load(d.H + oi, K, lane);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) shq[e][q].load(Hs[q] + oi, K, lane);
+            xq[e] = xrow[i < 0 ? 0 : i];                            // wave-uniform addresses
+            pq[e] = d.prop[i < 0 ? 0 : i];
+        };
+#pragma unroll
+        for (int e = 0; e < PF; ++e) issue(e, bcast_lane(it_c, e));
+        for (int64_t c = 0; c < c_end; ++c) {
+#pragma unroll 1
+            for (int t0 = 0; t0 < 64; t0 += RING) {
+#pragma unroll
+                for (int e = 0; e < RING; ++e) {
+                    const int t = t0 + e;
+                    const int32_t i = bcast_lane(it_c, t);
+                    if (i >= 0) {                                   // wave-uniform
+                        const RowT h_old = hq[e];
+                        float py = 0, pl = 0;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            py += w.v[r] * hq[e].v[r];
+                            pl += w.v[r] * w.v[r] + hq[e].v[r] * hq[e].v[r];
+                        }
+                        const float y = wave_sum(py), l2 = wave_sum(pl);
+                        const float p = pq[e];
+                        const float qq = xq[e] / (p >= d.clip ? p : d.clip);                 // r / dmax(p, M)
+                        loss_sum += qq * (1 - y) * (1 - y) + (1 - qq) * y * y + d.wd * l2;   // model.pyx:117
+                        const float cc = qq * (1 - y) + (1 - qq) * (0 - y);                  // model.pyx:131-139
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const float wv = w.v[r], hv = hq[e].v[r];
+                            const float gw = -(cc * hv) + d.wd * wv;
+                            const float gh = -(cc * wv) + d.wd * hv;
+                            float dummy = 0;
+                            if (RowT::packed || RowT::kof(lane, r) < K) {   // masked lanes hold zeros: keep 0/sqrt(0) out
+                                opt_update<float, OPT, true>(d.opt, w.v[r], OPT >= 1 ? sw[0].v[r] : dummy, OPT == 2 ? sw[NSA - 1].v[r] : dummy, gw);
+                                opt_update<float, OPT, true>(d.opt, hq[e].v[r], OPT >= 1 ? shq[e][0].v[r] : dummy,
+                                                             OPT == 2 ? shq[e][NSA - 1].v[r] : dummy, gh);
+                            }
+                        }
+                        gl_atomic_add_row<RowT, R>(d.H + (int64_t)i * K, hq[e], h_old, K, lane);
+#pragma unroll
+                        for (int q = 0; q < NS; ++q) shq[e][q].store(Hs[q] + (int64_t)i * K, K, lane);
+                    }
+                    const int tn = t + PF;
+                    issue((e + PF) % RING, tn < 64 ? bcast_lane(it_c, tn & 63) : bcast_lane(it_n, tn & 63));
+                }
+            }
+            it_c = it_n;
+            it_n = load_meta(c + 2);
+        }
+        w.store(d.W + u * K, K, lane);                              // this wave is the only writer of W[u]
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sw[q].store(Ws[q] + u * K, K, lane);
+    }
+    if (lane == 0) atomicAdd(loss_acc, (double)loss_sum);
+}
+
+template <int R, bool PACKED>
+void launch_relmf_step_opt(int opt, const RelStepDev &d, const int64_t *off, const int32_t *items, int32_t U, int32_t upw,
+                           double *loss, int grid, hipStream_t s) {
+    switch (opt) {
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_SGD, 8>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, 4>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss); break;
+    default: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_ADAM, 4>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss); break;
+    }
+}
+
+void launch_relmf_step(int K, int opt, const RelStepDev &d, const int64_t *off, const int32_t *items, int32_t U, int32_t upw,
+                       double *loss, int grid, hipStream_t s) {
+    if (K <= 64) launch_relmf_step_opt<1, false>(opt, d, off, items, U, upw, loss, grid, s);
+    else if (K == 128) launch_relmf_step_opt<2, true>(opt, d, off, items, U, upw, loss, grid, s);
+    else launch_relmf_step_opt<2, false>(opt, d, off, items, U, upw, loss, grid, s);
+}
+
 void launch_glove_step(int K, const GloveStepDev &d, const int32_t *c, const int32_t *x, const float *cnt, int64_t n,
                        int64_t cpw, double *loss, int grid, hipStream_t s) {
 #define CALL_(R_, P_) hipLaunchKernelGGL((glove_step_kernel<R_, P_, 8>), dim3(grid), dim3(256), 0, s, d, c, x, cnt, n, cpw, loss)
@@ -461,23 +685,93 @@ struct cymf_relmf {
     RelStore<float> f32;
     RelStore<double> f64;
     DeviceRng rng;
-    DevBuf<uint32_t> d_cells, d_sorted;
+    DevBuf<uint32_t> d_cells, d_sorted, d_ucnt;
+    DevBuf<unsigned long long> d_ucursor;
+    // step path (f32 throughput, K <= 128): the cells of epoch e+1 are generated and bucketed by user on
+    // side_stream while relmf_step_kernel works through epoch e; buffers double-buffered by epoch parity
+    bool step_path = false;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_bucketed[2] = {nullptr, nullptr}, ev_step_done[2] = {nullptr, nullptr};
+    DevBuf<int64_t> d_uoff[2];
+    DevBuf<int32_t> d_items[2];
+    int64_t epochs_prepared = 0, epoch_cursor = 0;
     DevBuf<double> d_loss;
     std::vector<uint32_t> h_cells;
     bool have_data = false, have_params = false;
 };
 
+// cells of epoch g: generate on the side stream, bucket by user into the buffers of parity g & 1
+static int relmf_prepare(cymf_relmf *h, int64_t g_want) {
+    const int64_t N = (int64_t)h->U * h->I;
+    while (h->epochs_prepared <= g_want) {
+        const int64_t g = h->epochs_prepared;
+        const int b = (int)(g & 1);
+        hipStream_t ss = h->side_stream;
+        CYMF_TRY(h->d_cells.alloc((size_t)N));
+        CYMF_TRY(h->d_ucnt.alloc((size_t)h->U));
+        CYMF_TRY(h->d_ucursor.alloc((size_t)h->U));
+        CYMF_TRY(h->d_uoff[b].alloc((size_t)h->U + 1));
+        CYMF_TRY(h->d_items[b].alloc((size_t)N));
+        if (g >= 2) CYMF_HIP(hipStreamWaitEvent(ss, h->ev_step_done[b], 0));   // buffers b were read by the step kernel of epoch g-2
+        CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, ss));
+        CYMF_TRY(h->d_ucnt.zero(ss));
+        const bool lds = h->U <= RELMF_LDS_USERS;
+        const int segs = (int)((N + RELMF_SEG - 1) / RELMF_SEG);
+        if (lds) {
+            const size_t sm_h = sizeof(uint32_t) * (size_t)((h->U + 1) / 2), sm_s = sizeof(uint32_t) * ((size_t)h->U + (size_t)((h->U + 1) / 2));
+            CYMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(relmf_hist_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_h));
+            CYMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(relmf_scatter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_s));
+            hipLaunchKernelGGL(relmf_hist_lds_kernel, dim3(segs), dim3(1024), sm_h, ss, h->d_cells.p, N, (uint32_t)h->I, h->U, h->d_ucnt.p);
+            hipLaunchKernelGGL(relmf_scan_kernel, dim3(1), dim3(1024), 0, ss, h->d_ucnt.p, h->U, h->d_uoff[b].p, h->d_ucursor.p);
+            hipLaunchKernelGGL(relmf_scatter_lds_kernel, dim3(segs), dim3(1024), sm_s, ss, h->d_cells.p, N, (uint32_t)h->I, h->U,
+                               h->d_ucursor.p, h->d_items[b].p);
+        } else {
+            hipLaunchKernelGGL(relmf_hist_kernel, dim3(ew_blocks(N)), dim3(256), 0, ss, h->d_cells.p, N, (uint32_t)h->I, h->d_ucnt.p);
+            hipLaunchKernelGGL(relmf_scan_kernel, dim3(1), dim3(1024), 0, ss, h->d_ucnt.p, h->U, h->d_uoff[b].p, h->d_ucursor.p);
+            hipLaunchKernelGGL(relmf_scatter_kernel, dim3(ew_blocks(N)), dim3(256), 0, ss, h->d_cells.p, N, (uint32_t)h->I, h->d_ucursor.p,
+                               h->d_items[b].p);
+        }
+        CYMF_HIP(hipGetLastError());
+        CYMF_HIP(hipEventRecord(h->ev_bucketed[b], ss));
+        h->epochs_prepared++;
+    }
+    return 0;
+}
+
 template <typename T>
 static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
     const int64_t N = (int64_t)h->U * h->I;   // relmf.pyx:120: one epoch = U*I draws with replacement
-    CYMF_TRY(h->d_cells.alloc((size_t)N));
-    CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, h->stream));
+    const bool stepped = h->mode == CYMF_MODE_THROUGHPUT && h->step_path && sizeof(T) == 4;
+    if (!stepped) {
+        CYMF_TRY(h->d_cells.alloc((size_t)N));
+        CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, h->stream));
+    }
     RelDev<T> d;
     d.W = st.W.p; d.H = st.H.p; d.W0 = st.W0.p; d.W1 = st.W1.p; d.H0 = st.H0.p; d.H1 = st.H1.p;
     d.X = st.X.p; d.prop = st.prop.p; d.K = h->K; d.I = h->I; d.wd = (T)h->wd; d.clip = (T)h->clip;
     d.opt = make_opt_params<T>(h->lr);
     CYMF_TRY(h->d_loss.zero(h->stream));
-    if (h->mode == CYMF_MODE_THROUGHPUT) {
+    if (h->mode == CYMF_MODE_THROUGHPUT && h->step_path) {
+        if constexpr (sizeof(T) == 4) {
+            const int64_t e = h->epoch_cursor;
+            const int b = (int)(e & 1);
+            CYMF_TRY(relmf_prepare(h, e));
+            CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_bucketed[b], 0));
+            CYMF_TRY(relmf_prepare(h, e + 1));   // next epoch's cells, concurrently with this epoch's updates
+            RelStepDev sd;
+            sd.W = st.W.p; sd.H = st.H.p; sd.W0 = st.W0.p; sd.W1 = st.W1.p; sd.H0 = st.H0.p; sd.H1 = st.H1.p;
+            sd.X = st.X.p; sd.prop = st.prop.p; sd.K = h->K; sd.I = h->I; sd.wd = (float)h->wd; sd.clip = (float)h->clip;
+            sd.opt = make_opt_params<float>(h->lr);
+            // whole users per wavefront; every user has about I draws, so equal user counts are equal work
+            const int64_t max_waves = 256 * 12;
+            const int32_t upw = (int32_t)std::max<int64_t>(1, ((int64_t)h->U + max_waves - 1) / max_waves);
+            const int64_t waves = ((int64_t)h->U + upw - 1) / upw;
+            launch_relmf_step(h->K, h->opt, sd, h->d_uoff[b].p, h->d_items[b].p, h->U, upw, h->d_loss.p, (int)((waves + 3) / 4), h->stream);
+            CYMF_HIP(hipGetLastError());
+            CYMF_HIP(hipEventRecord(h->ev_step_done[b], h->stream));
+            h->epoch_cursor++;
+        }
+    } else if (h->mode == CYMF_MODE_THROUGHPUT) {
         launch_relmf<T>(h->K, h->opt, d, h->d_cells.p, N, h->d_loss.p, hogwild_grid(N, 1.0 / std::min(h->U, h->I)), h->stream);
         CYMF_HIP(hipGetLastError());
     } else {
@@ -528,8 +822,20 @@ extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t
         for (DevBuf<double> *b : {&h->f64.W, &h->f64.H, &h->f64.W0, &h->f64.W1, &h->f64.H0, &h->f64.H1}) b->fine = 2;
     }
     int rc = h->d_loss.alloc(1);
-    if (!rc) rc = h->rng.init(seed, (uint64_t)U * (uint64_t)I, h->stream);   // relmf.pyx:128
-    if (rc) { (void)hipStreamDestroy(h->stream); delete h; return rc; }
+    h->step_path = mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && K <= 128 && !(getenv("CYMF_RELMF_NO_STEP") && getenv("CYMF_RELMF_NO_STEP")[0] == '1');
+    if (!rc && h->step_path) {
+        hipError_t e2 = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
+        for (int b = 0; b < 2 && e2 == hipSuccess; ++b) {
+            e2 = hipEventCreateWithFlags(&h->ev_bucketed[b], hipEventDisableTiming);
+            if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&h->ev_step_done[b], hipEventDisableTiming);
+        }
+        if (e2 != hipSuccess) rc = fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e2));
+    }
+    // relmf.pyx:128; >= 2M cells per epoch: chunked jump-ahead generator (rng.hip), else the one-workgroup walker.
+    // The generator lives on the stream that consumes it: the side stream on the step path.
+    if (!rc) rc = h->rng.init(seed, (uint64_t)U * (uint64_t)I, h->step_path ? h->side_stream : h->stream,
+                              /*parallel=*/(int64_t)U * I >= (int64_t)2 << 20);
+    if (rc) { (void)cymf_relmf_destroy(h); return rc; }
     *out = h;
     return 0;
 }
@@ -592,7 +898,13 @@ extern "C" int cymf_relmf_epochs(cymf_relmf *h, int32_t n_epochs, double *loss_o
 extern "C" int cymf_relmf_destroy(cymf_relmf *h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    for (int b = 0; b < 2; ++b) {
+        if (h->ev_bucketed[b]) (void)hipEventDestroy(h->ev_bucketed[b]);
+        if (h->ev_step_done[b]) (void)hipEventDestroy(h->ev_step_done[b]);
+    }
     delete h;
     return 0;
 }

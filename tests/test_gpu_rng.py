@@ -53,11 +53,13 @@ def test_range_limits_are_errors():
 
 
 @pytest.mark.parametrize("rng_range,n,skip", [(100000, 9_000_000, 0), (100000, 200_000, 4_193_280 * 2 - 100_000),
-                                              (3706, 5_000_000, 4_193_279), (40_000_000, 6_000_000, 11)])
+                                              (3706, 5_000_000, 4_193_279), (40_000_000, 6_000_000, 11),
+                                              (160_000_000, 3_000_000, 6_000_000), (300_000_000, 4_500_000, 0)])
 def test_chunked_jump_ahead_generator_vs_oracle(rng_range, n, skip):
     """skip + n >= 4M selects the parallel generator: chunk start states by the MT19937 jump-ahead
     polynomial (tools/gen_mt_jump.py), one workgroup per 4,193,280-word chunk, ordered gather.
-    range 4e7 rejects ~1% of the raw words (hundreds of rejections per chunk boundary case)."""
+    range 4e7 rejects ~1% of the raw words; 1.6e8 (the U*I of a 20000 x 8000 RelMF problem) 3.1% and 3e8 2.2%:
+    ~100 k rejections per chunk, the rejection list is sized from the range."""
     got = _lib.rng_fill_uniform(1234, rng_range, n, skip=skip)
     want = oracle.uniform_stream(1234, rng_range, n, skip=skip)
     assert np.array_equal(got, want)
