@@ -54,7 +54,7 @@ struct RelDev {
 };
 
 // One draw: cell index -> (u, i) = (cell / I, cell % I)  (relmf.pyx:144-146)
-template <typename T, int R, bool PACKED, int OPT>
+template <typename T, int R, bool PACKED, int OPT, bool HOG>
 __global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const uint32_t *__restrict__ cells, int64_t n,
                                                    double *__restrict__ loss_acc) {
     const int lane = lane_id();
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const uint32_t 
             const T gw = -(c * hv) + d.wd * wv;
             const T gh = -(c * wv) + d.wd * hv;
             T dummy = 0;
-            opt_update<T, OPT>(d.opt, w.v[q], OPT >= 1 ? sw[0].v[q] : dummy, OPT == 2 ? sw[1].v[q] : dummy, gw);
-            opt_update<T, OPT>(d.opt, h.v[q], OPT >= 1 ? sh[0].v[q] : dummy, OPT == 2 ? sh[1].v[q] : dummy, gh);
+            opt_update<T, OPT, HOG>(d.opt, w.v[q], OPT >= 1 ? sw[0].v[q] : dummy, OPT == 2 ? sw[1].v[q] : dummy, gw);
+            opt_update<T, OPT, HOG>(d.opt, h.v[q], OPT >= 1 ? sh[0].v[q] : dummy, OPT == 2 ? sh[1].v[q] : dummy, gh);
         }
         w.store(d.W + ou, K, lane);
         h.store(d.H + oi, K, lane);
@@ -394,8 +394,8 @@ __global__ void unpack2_kernel(const float2 *__restrict__ in, float *__restrict_
 // stays in cache, and the item rows come through a ring of loads issued PF slots ahead.  Every item is
 // equally popular here (uniform cells): with a few thousand wavefronts in flight each item row has
 // several holders at any time, so a slot ADDS its delta of H[i] (float atomics) instead of storing the
-// row back; the optimizer state of H[i] is stored plainly (a lost update there perturbs a running
-// average, a delta-sum of moments is unstable: see bpr.hip).
+// row back; AdaGrad's accumulator of H[i] is a sum of g^2 and is added to the same way, Adam's moments are
+// stored plainly (a lost update there perturbs a running average, a delta-sum of moments is unstable: see bpr.hip).
 __global__ void relmf_hist_kernel(const uint32_t *__restrict__ cells, int64_t n, uint32_t I, uint32_t *__restrict__ cnt) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -552,6 +552,7 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
                     const int32_t i = bcast_lane(it_c, t);
                     if (i >= 0) {                                   // wave-uniform
                         const RowT h_old = hq[e];
+                        const RowT acc_old = shq[e][0];             // (AdaGrad: the accumulator before this slot)
                         float py = 0, pl = 0;
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
@@ -576,8 +577,12 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
                             }
                         }
                         gl_atomic_add_row<RowT, R>(d.H + (int64_t)i * K, hq[e], h_old, K, lane);
+                        if constexpr (OPT == CYMF_OPT_ADAGRAD) {      // a sum of g^2: adding this slot's share is exact
+                            gl_atomic_add_row<RowT, R>(Hs[0] + (int64_t)i * K, shq[e][0], acc_old, K, lane);
+                        } else {
 #pragma unroll
-                        for (int q = 0; q < NS; ++q) shq[e][q].store(Hs[q] + (int64_t)i * K, K, lane);
+                            for (int q = 0; q < NS; ++q) shq[e][q].store(Hs[q] + (int64_t)i * K, K, lane);
+                        }
                     }
                     const int tn = t + PF;
                     issue((e + PF) % RING, tn < 64 ? bcast_lane(it_c, tn & 63) : bcast_lane(it_n, tn & 63));
@@ -627,20 +632,25 @@ void launch_glove_step(int K, const GloveStepDev &d, const int32_t *c, const int
         else { if (P__) { CALL(4, true); } else { CALL(4, false); } }                          \
     } while (0)
 
-template <typename T, int R, bool PACKED>
+template <typename T, int R, bool PACKED, bool HOG>
 void launch_relmf_opt(int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, double *loss, int grid,
                       hipStream_t s) {
     switch (opt) {
-    case CYMF_OPT_SGD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_SGD>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
-    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAGRAD>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
-    default: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAM>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_SGD, HOG>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAGRAD, HOG>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    default: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAM, HOG>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
     }
 }
 
+// hog: lock-free launch over all cells (Adam's moment clamp of rows.h on); false: one conflict-free level
 template <typename T>
 void launch_relmf(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, double *loss, int grid,
-                  hipStream_t s) {
-#define CALL_(R_, P_) launch_relmf_opt<T, R_, P_>(opt, d, cells, n, loss, grid, s)
+                  hipStream_t s, bool hog = false) {
+#define CALL_(R_, P_)                                                                 \
+    do {                                                                              \
+        if (hog) launch_relmf_opt<T, R_, P_, true>(opt, d, cells, n, loss, grid, s);  \
+        else launch_relmf_opt<T, R_, P_, false>(opt, d, cells, n, loss, grid, s);     \
+    } while (0)
     CYMF_DISPATCH_LAYOUT(K, CALL_);
 #undef CALL_
 }
@@ -772,7 +782,7 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
             h->epoch_cursor++;
         }
     } else if (h->mode == CYMF_MODE_THROUGHPUT) {
-        launch_relmf<T>(h->K, h->opt, d, h->d_cells.p, N, h->d_loss.p, hogwild_grid(N, 1.0 / std::min(h->U, h->I)), h->stream);
+        launch_relmf<T>(h->K, h->opt, d, h->d_cells.p, N, h->d_loss.p, hogwild_grid(N, 1.0 / std::min(h->U, h->I)), h->stream, /*hog=*/true);
         CYMF_HIP(hipGetLastError());
     } else {
         h->h_cells.resize((size_t)N);

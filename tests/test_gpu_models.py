@@ -50,6 +50,28 @@ def test_relmf_larger_vs_oracle_and_sparse_input():
     assert np.isfinite(mt.W).all() and mt.losses[0] == pytest.approx(loss, rel=2e-2)
 
 
+@pytest.mark.parametrize("optimizer,lr", [("sgd", 0.02), ("adagrad", 0.05), ("adam", 0.002)])
+def test_relmf_step_path_tracks_the_sequential_oracle(optimizer, lr):
+    """Throughput mode at a size that takes the chunked index stream (>= 2M cells) and the per-epoch device
+    bucketing (relmf_step_kernel): the same cells in another order, lock-free -- epoch losses and factor
+    norms follow the sequential oracle; the old one-sample-per-wave kernel (CYMF_RELMF_NO_STEP) agrees too."""
+    rs = np.random.RandomState(3)
+    U, I, K = 1500, 1400, 32
+    Xd = (rs.rand(U, I) < 0.03).astype(np.float64)
+    prop = np.maximum(Xd.mean(axis=0) / Xd.mean(axis=0).max(), 1e-5) ** 0.5
+    W, H = oracle.reference_init(U, I, K)
+    om = oracle.RelMf(W, H, optimizer, lr, 0.01, 0.1)
+    want = [om.epoch(Xd, prop) for _ in range(2)]
+    m = RelMF(K, 0.1, lr, optimizer, 0.01)
+    m.fit(Xd, num_epochs=2, num_threads=0)
+    assert np.isfinite(m.W).all() and np.isfinite(m.H).all()
+    np.testing.assert_allclose(m.losses, want, rtol=3e-2)
+    # Adam's normalised steps make the lock-free item side run ahead of the sequential one (every concurrent holder
+    # of an item row adds a full-size step): the objective agrees, the norm of H ends ~35 % larger at this rate
+    tol_h = 0.5 if optimizer == "adam" else 0.15
+    assert abs(np.linalg.norm(m.W) / np.linalg.norm(W) - 1) < 0.15 and abs(np.linalg.norm(m.H) / np.linalg.norm(H) - 1) < tol_h
+
+
 # ------------------------------------------------------------------ GloVe
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("K", [16, 100])
