@@ -100,6 +100,82 @@ __global__ __launch_bounds__(256) void bpr_level_kernel(BprDev<T> d, const int32
     if (lane == 0) atomicAdd(loss_acc, (double)loss);
 }
 
+// ---------------------------------------------------------------- EXACT: dataflow execution of the sequential order
+// One launch per level costs a launch gap per level (~6 000 per epoch on ml-1m-shaped data).  The same
+// dependence structure can be executed by ONE launch: triplet l may run as soon as the earlier triplets that
+// touch its three rows are done.  The host numbers the accesses of every row in sequential order ("turns":
+// triplet l is access number ku[l] of W[u], ki[l] of H[i], kj[l] of H[j]); a per-row counter on the device
+// counts finished accesses; a wavefront takes the next triplet of the order from a dispenser, waits until the
+// three counters show its turn numbers, updates the rows and bumps the counters.  Triplets are handed out in
+// order to whichever wavefront asks next, so the smallest unfinished triplet is always held by a RUNNING
+// wavefront and never waits on anything unfinished: the schedule cannot deadlock, whatever part of the grid is
+// resident (no cooperative launch needed: that costs ~40 ms of queue draining per call here); a spin limit
+// turns a broken schedule into an error instead of a hang.  Rows travel between wavefronts on different
+// XCDs: the tables are uncached memory in this mode, the counters are bumped after an agent-scope release
+// fence and the rows are loaded after an acquire fence (which also drops the CU's L1 lines).
+constexpr unsigned int TICKET_SPIN_LIMIT = 1u << 20;   // polls of >= 0.2 us each; a healthy schedule waits < 10 ms for a turn
+
+__device__ __forceinline__ bool ticket_wait(const unsigned int *ctr, unsigned int turn) {
+    unsigned int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != turn) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > TICKET_SPIN_LIMIT) return false;
+    }
+    return true;
+}
+
+template <typename T, int R, bool PACKED, int OPT>
+__global__ __launch_bounds__(256) void bpr_ticket_kernel(BprDev<T> d, const int32_t *__restrict__ tu,
+                                                        const int32_t *__restrict__ ti, const int32_t *__restrict__ tj,
+                                                        const uint32_t *__restrict__ ku, const uint32_t *__restrict__ ki,
+                                                        const uint32_t *__restrict__ kj, int64_t n,
+                                                        unsigned int *doneW, unsigned int *doneH,
+                                                        unsigned long long *next, double *__restrict__ loss_acc, int *err) {
+    const int lane = lane_id();
+    const int K = d.K;
+    constexpr int NS = opt_num_states(OPT);
+    double loss_sum = 0.0;
+    auto grab = [&]() -> int64_t {
+        unsigned long long v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
+    int64_t l = grab();
+    while (l < n) {
+        const int64_t l_next = grab();   // asked for early: its latency hides behind this triplet's waits and loads
+        const int32_t u = tu[l], i = ti[l], j = tj[l];
+        const bool ok = ticket_wait(doneW + u, ku[l]) && ticket_wait(doneH + i, ki[l]) && ticket_wait(doneH + j, kj[l]);
+        if (!ok) {   // cannot happen with a consistent schedule; never hang the device on a bad one
+            if (lane == 0) atomicExch(err, 1);
+            break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int64_t ou = (int64_t)u * K, oi = (int64_t)i * K, oj = (int64_t)j * K;
+        Row<T, R, PACKED> w, hi, hj, sw[NS ? NS : 1], shi[NS ? NS : 1], shj[NS ? NS : 1];
+        w.load(d.W + ou, K, lane);
+        hi.load(d.H + oi, K, lane);
+        hj.load(d.H + oj, K, lane);
+        if constexpr (NS >= 1) { sw[0].load(d.W0 + ou, K, lane); shi[0].load(d.H0 + oi, K, lane); shj[0].load(d.H0 + oj, K, lane); }
+        if constexpr (NS >= 2) { sw[1].load(d.W1 + ou, K, lane); shi[1].load(d.H1 + oi, K, lane); shj[1].load(d.H1 + oj, K, lane); }
+        loss_sum += (double)bpr_update_rows<T, R, PACKED, OPT>(d, w, hi, hj, sw, shi, shj);
+        w.store(d.W + ou, K, lane);
+        hi.store(d.H + oi, K, lane);
+        hj.store(d.H + oj, K, lane);
+        if constexpr (NS >= 1) { sw[0].store(d.W0 + ou, K, lane); shi[0].store(d.H0 + oi, K, lane); shj[0].store(d.H0 + oj, K, lane); }
+        if constexpr (NS >= 2) { sw[1].store(d.W1 + ou, K, lane); shi[1].store(d.H1 + oi, K, lane); shj[1].store(d.H1 + oj, K, lane); }
+        // every lane's stores are complete (the fence waits for them wave-wide) before lane 0 publishes the turn
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) {
+            __hip_atomic_fetch_add(doneW + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(doneH + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(doneH + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        l = l_next;
+    }
+    if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
+}
+
 // ---------------------------------------------------------------- THROUGHPUT: resolve negatives of a slot range
 // The reference asks `negative in user_positives[user]` of a std::set per user (bpr.pyx:140,166).
 // Device form: ONE open-addressing table over all (user, item) pairs of X (64-bit keys, load <= 1/2,
@@ -546,9 +622,17 @@ struct cymf_bpr {
     bool epoch_sampled = false;     // slot_neg holds epoch_cursor's negatives
 
     // exact mode scratch
-    std::vector<uint32_t> h_draws;
+    uint32_t *h_draws = nullptr;   // pinned (hipHostMalloc): the exact mode reads the epoch's draws on the host
+    int64_t h_draws_cap = 0;
     std::vector<int32_t> h_last_neg;
     DevBuf<int32_t> d_tu, d_ti, d_tj;
+    // exact mode, dataflow execution (bpr_ticket_kernel): turn numbers per triplet, finished-access counters per row
+    bool exact_tickets = true;   // CYMF_BPR_EXACT_LEVELS=1 selects one launch per level instead
+    std::vector<uint64_t> h_pos_bits;   // exact mode: U x I membership bitmap when it fits 256 MB (else binary search of the CSR row)
+    DevBuf<uint32_t> d_ku, d_ki, d_kj, d_done;
+    DevBuf<unsigned long long> d_next;
+    DevBuf<int> d_err;
+    int n_cu = 0;
 
     // throughput mode
     int32_t steps_per_epoch = 1;
@@ -631,6 +715,41 @@ void launch_level(int K, int opt, const BprDev<T> &d, const int32_t *tu, const i
 
 
 
+// one launch, about as many workgroups as fit the device at once (more would only queue up behind them)
+template <typename T, int R, bool PACKED, int OPT>
+int launch_ticket_inst(const BprDev<T> &d, const int32_t *tu, const int32_t *ti, const int32_t *tj, const uint32_t *ku,
+                       const uint32_t *ki, const uint32_t *kj, int64_t n, unsigned int *doneW, unsigned int *doneH,
+                       unsigned long long *next, double *loss, int *err, int n_cu, hipStream_t s) {
+    int64_t blocks = (int64_t)2 * n_cu;            // 8 waves per CU are plenty: the schedule is a latency chain
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (n + 3) / 4));
+    hipLaunchKernelGGL((bpr_ticket_kernel<T, R, PACKED, OPT>), dim3((unsigned)blocks), dim3(256), 0, s, d, tu, ti, tj, ku, ki, kj, n,
+                       doneW, doneH, next, loss, err);
+    CYMF_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int R, bool PACKED>
+int launch_ticket_opt(int opt, const BprDev<T> &d, const int32_t *tu, const int32_t *ti, const int32_t *tj, const uint32_t *ku,
+                      const uint32_t *ki, const uint32_t *kj, int64_t n, unsigned int *doneW, unsigned int *doneH,
+                      unsigned long long *next, double *loss, int *err, int n_cu, hipStream_t s) {
+    switch (opt) {
+    case CYMF_OPT_SGD: return launch_ticket_inst<T, R, PACKED, CYMF_OPT_SGD>(d, tu, ti, tj, ku, ki, kj, n, doneW, doneH, next, loss, err, n_cu, s);
+    case CYMF_OPT_ADAGRAD: return launch_ticket_inst<T, R, PACKED, CYMF_OPT_ADAGRAD>(d, tu, ti, tj, ku, ki, kj, n, doneW, doneH, next, loss, err, n_cu, s);
+    default: return launch_ticket_inst<T, R, PACKED, CYMF_OPT_ADAM>(d, tu, ti, tj, ku, ki, kj, n, doneW, doneH, next, loss, err, n_cu, s);
+    }
+}
+
+template <typename T>
+int launch_ticket(int K, int opt, const BprDev<T> &d, const int32_t *tu, const int32_t *ti, const int32_t *tj, const uint32_t *ku,
+                  const uint32_t *ki, const uint32_t *kj, int64_t n, unsigned int *doneW, unsigned int *doneH,
+                  unsigned long long *next, double *loss, int *err, int n_cu, hipStream_t s) {
+    int rc = 0;
+#define CALL_(R_, P_) rc = launch_ticket_opt<T, R_, P_>(opt, d, tu, ti, tj, ku, ki, kj, n, doneW, doneH, next, loss, err, n_cu, s)
+    CYMF_DISPATCH_LAYOUT(K, CALL_);
+#undef CALL_
+    return rc;
+}
+
 template <int R, bool PACKED, int STEP_PF, int STEP_PFJ = STEP_PF>
 void launch_step_opt(int opt, const BprDev<float> &d, const int32_t *su, const int32_t *si, const int32_t *sn,
                      int64_t b, int64_t e, int64_t cpw, int xs, const int64_t *wr, int64_t nw, double *loss, unsigned long long *perf, int grid_blocks, hipStream_t s) {
@@ -698,15 +817,78 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
     const int64_t e = h->epoch_cursor;
     const int b = (int)(e & 1);
     CYMF_TRY(request_epoch_draws(h, e));
-    h->h_draws.resize((size_t)h->N_global);
+    if (h->h_draws_cap < h->N_global) {
+        if (h->h_draws) (void)hipHostFree(h->h_draws);
+        h->h_draws = nullptr;
+        CYMF_HIP(hipHostMalloc((void **)&h->h_draws, (size_t)h->N_global * sizeof(uint32_t)));
+        h->h_draws_cap = h->N_global;
+    }
     CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_gen[b], 0));
-    CYMF_HIP(hipMemcpyAsync(h->h_draws.data(), h->d_draws[b].p, (size_t)h->N_global * sizeof(uint32_t),
+    CYMF_HIP(hipMemcpyAsync(h->h_draws, h->d_draws[b].p, (size_t)h->N_global * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
     CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->stream));
 
-    // level scheduling (host): level(l) = 1 + max(level of the last earlier triplet touching u, i or j)
     const int64_t N = h->N;
+    if (h->exact_tickets) {
+        // turns (host): triplet l is access number ku of W[u], ki of H[i], kj of H[j] in sequential order
+        std::vector<uint32_t> cntW((size_t)h->U, 0u), cntH((size_t)h->I, 0u);
+        h->h_last_neg.assign((size_t)N, -1);
+        std::vector<int32_t> tu, ti, tj;
+        std::vector<uint32_t> ku, ki, kj;
+        tu.reserve((size_t)N); ti.reserve((size_t)N); tj.reserve((size_t)N);
+        ku.reserve((size_t)N); ki.reserve((size_t)N); kj.reserve((size_t)N);
+        for (int64_t l = 0; l < N; ++l) {
+            const int32_t u = h->h_users[l], i = h->h_pos_items[l];
+            const int32_t j = (int32_t)h->h_draws[h->h_gpos[l]];
+            const bool positive = h->h_pos_bits.empty() ? csr_has(h->h_indptr, h->h_indices, u, j)
+                                                        : (h->h_pos_bits[((size_t)u * h->I + j) >> 6] >> (((size_t)u * h->I + j) & 63)) & 1;
+            if (positive) continue;                                    // bpr.pyx:166-167
+            h->h_last_neg[l] = j;
+            tu.push_back(u); ti.push_back(i); tj.push_back(j);
+            ku.push_back(cntW[u]++); ki.push_back(cntH[i]++); kj.push_back(cntH[j]++);
+        }
+        const int64_t n_perf = (int64_t)tu.size(), n_skipped = N - n_perf;
+        CYMF_TRY(h->d_tu.upload_into(tu.data(), tu.size(), (size_t)N, h->stream));
+        CYMF_TRY(h->d_ti.upload_into(ti.data(), ti.size(), (size_t)N, h->stream));
+        CYMF_TRY(h->d_tj.upload_into(tj.data(), tj.size(), (size_t)N, h->stream));
+        CYMF_TRY(h->d_ku.upload_into(ku.data(), ku.size(), (size_t)N, h->stream));
+        CYMF_TRY(h->d_ki.upload_into(ki.data(), ki.size(), (size_t)N, h->stream));
+        CYMF_TRY(h->d_kj.upload_into(kj.data(), kj.size(), (size_t)N, h->stream));
+        CYMF_TRY(h->d_done.alloc((size_t)h->U + (size_t)h->I));
+        CYMF_TRY(h->d_done.zero(h->stream));
+        CYMF_TRY(h->d_err.alloc(1));
+        CYMF_TRY(h->d_err.zero(h->stream));
+        CYMF_TRY(h->d_next.alloc(1));
+        CYMF_TRY(h->d_next.zero(h->stream));
+        CYMF_TRY(h->d_loss.zero(h->stream));
+        BprDev<T> d = st.view(h->K, h->wd, h->lr);
+        hipEvent_t p0 = nullptr, p1 = nullptr;
+        if (h->profiling) {
+            CYMF_HIP(hipEventCreate(&p0)); CYMF_HIP(hipEventCreate(&p1));
+            CYMF_HIP(hipEventRecord(p0, h->stream));
+        }
+        if (n_perf > 0)
+            CYMF_TRY(launch_ticket<T>(h->K, h->opt, d, h->d_tu.p, h->d_ti.p, h->d_tj.p, h->d_ku.p, h->d_ki.p, h->d_kj.p, n_perf,
+                                      h->d_done.p, h->d_done.p + h->U, h->d_next.p, h->d_loss.p, h->d_err.p, h->n_cu, h->stream));
+        if (h->profiling) {
+            CYMF_HIP(hipEventRecord(p1, h->stream));
+            h->prof_events.emplace_back(p0, p1);
+            h->prof_launches += 1;
+            h->prof_units += n_perf;
+        }
+        int err = 0;
+        CYMF_HIP(hipMemcpyAsync(&err, h->d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        double loss = 0;
+        CYMF_TRY(fetch_loss(h, &loss));
+        if (err) return fail(CYMF_ERR_HIP, "exact mode: a wavefront waited past the spin limit for its turn (inconsistent schedule)");
+        if (loss_out) *loss_out = N ? loss / (double)N : 0.0;   // bpr.pyx:171
+        h->performed += n_perf;
+        h->skipped += n_skipped;
+        h->epoch_cursor++;
+        return 0;
+    }
+    // level scheduling (host): level(l) = 1 + max(level of the last earlier triplet touching u, i or j)
     std::vector<int32_t> lastW((size_t)h->U, 0), lastH((size_t)h->I, 0), level((size_t)N, 0);
     h->h_last_neg.assign((size_t)N, -1);
     int32_t n_levels = 0;
@@ -1078,6 +1260,18 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
         const int f = getenv("CYMF_BPR_MEMTYPE") ? atoi(getenv("CYMF_BPR_MEMTYPE")) : 2;
         h->f32.W.fine = h->f32.H.fine = h->f32.W0.fine = h->f32.W1.fine = h->f32.H0.fine = h->f32.H1.fine = f;
     }
+    if (mode == CYMF_MODE_EXACT) {
+        if (const char *el = getenv("CYMF_BPR_EXACT_LEVELS")) h->exact_tickets = !(el[0] == '1');
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+        if (h->n_cu <= 0) h->exact_tickets = false;
+        if (h->exact_tickets) {   // rows are handed between wavefronts of one kernel, across XCDs
+            for (DevBuf<float> *b : {&h->f32.W, &h->f32.H, &h->f32.W0, &h->f32.W1, &h->f32.H0, &h->f32.H1}) b->fine = 2;
+            for (DevBuf<double> *b : {&h->f64.W, &h->f64.H, &h->f64.W0, &h->f64.W1, &h->f64.H0, &h->f64.H1}) b->fine = 2;
+            h->d_done.fine = 2;
+            h->d_next.fine = 2;
+        }
+    }
     if (const char *e3 = getenv("CYMF_BPR_XCD_STRIDE")) h->xcd_stride = std::max(1, atoi(e3));
     if (const char *e4 = getenv("CYMF_BPR_DIAG")) h->xcd_stride |= atoi(e4) << 8;
     if (const char *e6 = getenv("CYMF_BPR_PF")) h->step_pf = atoi(e6);   // 8 (default), 84, 164, 168 = (PF, PFJ) pairs
@@ -1139,6 +1333,15 @@ extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_
         h->rng_ready = true;
     }
     if (h->mode == CYMF_MODE_THROUGHPUT) CYMF_TRY(build_throughput_layout(h));
+    h->h_pos_bits.clear();
+    if (h->mode == CYMF_MODE_EXACT && (uint64_t)h->U * (uint64_t)h->I <= (1ull << 31)) {   // user_positives (bpr.pyx:146-147) as a bitmap
+        h->h_pos_bits.assign((size_t)(((uint64_t)h->U * h->I + 63) >> 6), 0ull);
+        for (int32_t u = 0; u < h->U; ++u)
+            for (int32_t p = indptr[u]; p < indptr[u + 1]; ++p) {
+                const size_t bit = (size_t)u * h->I + indices[p];
+                h->h_pos_bits[bit >> 6] |= 1ull << (bit & 63);
+            }
+    }
     h->have_data = true;
     return 0;
 }
@@ -1296,6 +1499,7 @@ extern "C" int cymf_bpr_destroy(cymf_bpr *h) {
     }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->rng_stream) (void)hipStreamDestroy(h->rng_stream);
+    if (h->h_draws) (void)hipHostFree(h->h_draws);
     delete h;
     return 0;
 }

@@ -75,6 +75,13 @@ struct DevBuf {
         n = count;
         return 0;
     }
+    // keep the allocation while it is large enough (per-epoch payloads whose size varies a little)
+    int reserve(size_t count) { return (p && n >= count) ? 0 : alloc(count); }
+    int upload_into(const T *src, size_t count, size_t capacity, hipStream_t s = nullptr) {
+        CYMF_TRY(reserve(capacity > count ? capacity : count));
+        if (count) CYMF_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return 0;
+    }
     int upload(const T *src, size_t count, hipStream_t s = nullptr) {
         CYMF_TRY(alloc(count));
         if (count) CYMF_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));

@@ -725,7 +725,7 @@ static int relmf_prepare(cymf_relmf *h, int64_t g_want) {
         if (g >= 2) CYMF_HIP(hipStreamWaitEvent(ss, h->ev_step_done[b], 0));   // buffers b were read by the step kernel of epoch g-2
         CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, ss));
         CYMF_TRY(h->d_ucnt.zero(ss));
-        const bool lds = h->U <= RELMF_LDS_USERS;
+        const bool lds = h->U <= RELMF_LDS_USERS && !(getenv("CYMF_RELMF_NO_LDS") && getenv("CYMF_RELMF_NO_LDS")[0] == '1');
         const int segs = (int)((N + RELMF_SEG - 1) / RELMF_SEG);
         if (lds) {
             const size_t sm_h = sizeof(uint32_t) * (size_t)((h->U + 1) / 2), sm_s = sizeof(uint32_t) * ((size_t)h->U + (size_t)((h->U + 1) / 2));

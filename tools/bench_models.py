@@ -101,9 +101,22 @@ if "relmf" in what:
 
 if "exact" in what:
     X, K = synthetic.config_matrix("C2")
+    rs = np.random.RandomState(5)
+    r, c = X.nonzero()
+    p = rs.permutation(len(r))
+    users, pos = r[p].astype(np.int32), c[p].astype(np.int32)
+    W, H = init(X.shape[0], X.shape[1], K)
     for opt in ("sgd", "adam"):
-        m = BPR(K, 0.01, opt, 0.01)
+        t = BprTrainer(X.shape[0], X.shape[1], K, opt, 0.01, 0.01, dtype="float64", mode="exact")
+        t.set_data(users, pos, X.indptr.astype(np.int32), X.indices.astype(np.int32))
+        t.upload(W, H)
+        t.epochs(1)
+        t.set_profiling(True)
+        t.kernel_time()
         t0 = time.perf_counter()
-        m.fit(X, num_epochs=3, num_threads=1, verbose=False)
-        dt = (time.perf_counter() - t0) / 3
-        print(f"BPR exact C2 {opt}: {dt*1e3:.0f} ms/epoch ({X.nnz/dt/1e6:.2f} M triplets/s, sequential-order parity mode)", flush=True)
+        t.epochs(5)
+        dt = (time.perf_counter() - t0) / 5
+        k_ms, launches, units = t.kernel_time()
+        print(f"BPR exact C2 {opt} f64: {dt*1e3:.1f} ms/epoch ({X.nnz/dt/1e6:.2f} M triplets/s, sequential-order parity mode); "
+              f"device {k_ms/5:.1f} ms/epoch in {launches/5:.0f} launches", flush=True)
+        t.close()
