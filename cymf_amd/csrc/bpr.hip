@@ -535,6 +535,7 @@ int upload_f64(DevBuf<T> &dst, const double *src, size_t n, hipStream_t s) {
         CYMF_HIP(hipMemcpyAsync(dst.p, src, n * sizeof(double), hipMemcpyHostToDevice, s));
     } else {
         DevBuf<double> tmp;
+        tmp.fine = staging_memtype();
         CYMF_TRY(tmp.alloc(n));
         CYMF_HIP(hipMemcpyAsync(tmp.p, src, n * sizeof(double), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(cast_from_f64_kernel<T>, dim3(ew_blocks((int64_t)n)), dim3(256), 0, s, tmp.p, dst.p, (int64_t)n);
@@ -551,6 +552,7 @@ int download_f64(const DevBuf<T> &src, double *dst, size_t n, hipStream_t s) {
         CYMF_HIP(hipStreamSynchronize(s));
     } else {
         DevBuf<double> tmp;
+        tmp.fine = staging_memtype();
         CYMF_TRY(tmp.alloc(n));
         hipLaunchKernelGGL(cast_to_f64_kernel<T>, dim3(ew_blocks((int64_t)n)), dim3(256), 0, s, src.p, tmp.p, (int64_t)n);
         CYMF_HIP(hipGetLastError());

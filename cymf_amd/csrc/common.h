@@ -34,7 +34,8 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 int use_device(int device);   // validates + hipSetDevice; CYMF_ERR_NO_DEVICE if none
-int default_memtype();        // CYMF_DEFAULT_MEMTYPE (0 coarse, 1 fine-grained = default, 2 uncached), read once
+int staging_memtype();        // CYMF_STAGING_MEMTYPE, default 2 (uncached): buffers a kernel fills and a copy engine reads, or vice versa
+int default_memtype();        // CYMF_DEFAULT_MEMTYPE (0 coarse, 1 fine-grained, 2 uncached = default), read once
 
 // ------------------------------------------------------------------ device memory
 template <typename T>
@@ -50,16 +51,16 @@ struct DevBuf {
         p = nullptr;
         n = 0;
     }
-    // Memory type.  -1 = the library default (default_memtype(): fine-grained), 0 = coarse-grained (hipMalloc),
+    // Memory type.  -1 = the library default (default_memtype(): uncached), 0 = coarse-grained (hipMalloc),
     // 1 = hipDeviceMallocFinegrained, 2 = hipDeviceMallocUncached.
-    //   * Fine-grained is the default because coarse-grained buffers handed from one kernel to the next were
-    //     observed STALE on some MI355X boxes: a consumer kernel on another XCD read lines its L2 had kept from an
-    //     earlier life of the same address (a freed buffer, the previous epoch's draws) although producer and
-    //     consumer were ordered on one stream -- intermittent, per box, gone with fine-grained or uncached
-    //     hand-off buffers (tests/test_gpu_dist.py history).  Fine-grained memory is still cached
-    //     inside a kernel; it costs nothing measurable on the streaming and gather paths here.
-    //   * Uncached (2) is for tables that wavefronts of ONE kernel update concurrently from all 8 XCDs
-    //     (HOGWILD): the per-XCD L2s are not coherent with each other inside a kernel for any cached type.
+    //   * Tables that wavefronts of ONE kernel update concurrently from all 8 XCDs (HOGWILD, the exact mode's row
+    //     hand-offs) must be uncached: the per-XCD L2s are not coherent with each other inside a kernel.
+    //   * Everything else is uncached too, because cached buffers were observed STALE on some MI355X boxes at the
+    //     seams between kernels and copies: negatives resolved from the previous epoch's draws, a download
+    //     staging buffer arriving on the host with rows of another matrix, host-read draws that did not match the
+    //     stream (DESIGN.md 2 lists the incidents; intermittent, per box, dependent on the allocation history of
+    //     the process, gone with uncached buffers).  The kernels here stream or gather with little L2 reuse, so
+    //     this costs 0-3 % (RelMF 10 %); CYMF_DEFAULT_MEMTYPE=1 / 0 restores cached buffers for experiments.
     int fine = -1;
     int alloc(size_t count) {
         if (count == n && p) return 0;

@@ -36,11 +36,20 @@ static int device_count_quiet() {
     return n;
 }
 
+int staging_memtype() {
+    static const int mt = [] {
+        const char *e = getenv("CYMF_STAGING_MEMTYPE");
+        const int v = e ? atoi(e) : 2;
+        return v < 0 || v > 2 ? 2 : v;
+    }();
+    return mt;
+}
+
 int default_memtype() {
     static const int mt = [] {
         const char *e = getenv("CYMF_DEFAULT_MEMTYPE");
-        const int v = e ? atoi(e) : 1;
-        return v < 0 || v > 2 ? 1 : v;
+        const int v = e ? atoi(e) : 2;
+        return v < 0 || v > 2 ? 2 : v;
     }();
     return mt;
 }

@@ -32,6 +32,15 @@ struct Row {
             }
         }
     }
+    // Agent-scope atomic loads, element by element: a row that other wavefronts update with float atomics is read
+    // from where those atomics are performed, not from a cache level they bypass.
+    __device__ __forceinline__ void load_coherent(const T *base, int K, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = kof(lane, r);
+            v[r] = (PACKED || k < K) ? __hip_atomic_load(base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
+        }
+    }
     __device__ __forceinline__ void store(T *__restrict__ base, int K, int lane) const {
         if constexpr (PACKED) {
             Vec t;

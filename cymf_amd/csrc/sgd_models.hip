@@ -498,12 +498,13 @@ struct RelStepDev {
     int64_t I;
     float wd, clip;
     OptParams<float> opt;
+    int coherent;   // read the item rows with agent-scope atomic loads (CYMF_RELMF_COHERENT_LOADS, default 1)
 };
 
 template <int R, bool PACKED, int OPT, int PF>
 __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int64_t *__restrict__ off,
                                                         const int32_t *__restrict__ items, int32_t U,
-                                                        int32_t users_per_wave, double *__restrict__ loss_acc) {
+                                                        int32_t users_per_wave, double *__restrict__ loss_acc, int *err) {
     using RowT = Row<float, R, PACKED>;
     constexpr int NS = opt_num_states(OPT);
     constexpr int NSA = NS ? NS : 1;
@@ -517,9 +518,18 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
     float *const Ws[2] = {d.W0, d.W1};
     float *const Hs[2] = {d.H0, d.H1};
     float loss_sum = 0.0f;
+    // The wavefront's users take turns of TURN slots each instead of being finished one after the other: a user's
+    // ~I draws in one block would let the item side (and AdaGrad's accumulators most of all) see the users in
+    // a few long blocks, far from the random interleaving of the sequential order (measured: norm of H x2.2 with
+    // nine users per wavefront back to back, 0.97 with every user on its own wavefront).
+    constexpr int64_t TURN = 256;
+    for (int64_t turn0 = 0;; turn0 += TURN) {
+    bool any = false;
     for (int64_t u = u_begin; u < u_end; ++u) {
-        const int64_t s_begin = off[u], s_end = off[u + 1];
+        const int64_t s_begin = off[u] + turn0;
+        const int64_t s_end = off[u + 1] < s_begin + TURN ? off[u + 1] : s_begin + TURN;
         if (s_begin >= s_end) continue;
+        any = true;
         const int64_t c_end = (s_end - s_begin + 63) >> 6;
         const float *xrow = d.X + u * d.I;
         RowT w, sw[NSA];
@@ -528,14 +538,16 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
         for (int q = 0; q < NS; ++q) sw[q].load(Ws[q] + u * K, K, lane);
         auto load_meta = [&](int64_t c) -> int32_t {
             const int64_t my = s_begin + (c << 6) + lane;
-            return (c < c_end && my < s_end) ? items[my] : -1;
+            int32_t it = (c < c_end && my < s_end) ? items[my] : -1;
+            if (it >= (int32_t)d.I) { atomicExch(err, 1); it = -1; }   // a broken bucketing must not become a wild access
+            return it;
         };
         int32_t it_c = load_meta(0), it_n = load_meta(1);
         RowT hq[RING], shq[RING][NSA];
         float xq[RING], pq[RING];
         auto issue = [&](int e, int32_t i) {
             const int64_t oi = (int64_t)(i < 0 ? 0 : i) * K;
-            hq[e].load(d.H + oi, K, lane);
+            if (d.coherent) hq[e].load_coherent(d.H + oi, K, lane); else hq[e].load(d.H + oi, K, lane);
 #pragma unroll
             for (int q = 0; q < NS; ++q) shq[e][q].load(Hs[q] + oi, K, lane);
             xq[e] = xrow[i < 0 ? 0 : i];                            // wave-uniform addresses
@@ -595,24 +607,26 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
 #pragma unroll
         for (int q = 0; q < NS; ++q) sw[q].store(Ws[q] + u * K, K, lane);
     }
+    if (!any) break;
+    }
     if (lane == 0) atomicAdd(loss_acc, (double)loss_sum);
 }
 
 template <int R, bool PACKED>
 void launch_relmf_step_opt(int opt, const RelStepDev &d, const int64_t *off, const int32_t *items, int32_t U, int32_t upw,
-                           double *loss, int grid, hipStream_t s) {
+                           double *loss, int *err, int grid, hipStream_t s) {
     switch (opt) {
-    case CYMF_OPT_SGD: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_SGD, 8>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss); break;
-    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, 4>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss); break;
-    default: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_ADAM, 4>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss); break;
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_SGD, 8>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss, err); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_ADAGRAD, 4>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss, err); break;
+    default: hipLaunchKernelGGL((relmf_step_kernel<R, PACKED, CYMF_OPT_ADAM, 4>), dim3(grid), dim3(256), 0, s, d, off, items, U, upw, loss, err); break;
     }
 }
 
 void launch_relmf_step(int K, int opt, const RelStepDev &d, const int64_t *off, const int32_t *items, int32_t U, int32_t upw,
-                       double *loss, int grid, hipStream_t s) {
-    if (K <= 64) launch_relmf_step_opt<1, false>(opt, d, off, items, U, upw, loss, grid, s);
-    else if (K == 128) launch_relmf_step_opt<2, true>(opt, d, off, items, U, upw, loss, grid, s);
-    else launch_relmf_step_opt<2, false>(opt, d, off, items, U, upw, loss, grid, s);
+                       double *loss, int *err, int grid, hipStream_t s) {
+    if (K <= 64) launch_relmf_step_opt<1, false>(opt, d, off, items, U, upw, loss, err, grid, s);
+    else if (K == 128) launch_relmf_step_opt<2, true>(opt, d, off, items, U, upw, loss, err, grid, s);
+    else launch_relmf_step_opt<2, false>(opt, d, off, items, U, upw, loss, err, grid, s);
 }
 
 void launch_glove_step(int K, const GloveStepDev &d, const int32_t *c, const int32_t *x, const float *cnt, int64_t n,
@@ -706,6 +720,7 @@ struct cymf_relmf {
     DevBuf<int32_t> d_items[2];
     int64_t epochs_prepared = 0, epoch_cursor = 0;
     DevBuf<double> d_loss;
+    DevBuf<int> d_err;
     std::vector<uint32_t> h_cells;
     bool have_data = false, have_params = false;
 };
@@ -772,11 +787,21 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
             sd.W = st.W.p; sd.H = st.H.p; sd.W0 = st.W0.p; sd.W1 = st.W1.p; sd.H0 = st.H0.p; sd.H1 = st.H1.p;
             sd.X = st.X.p; sd.prop = st.prop.p; sd.K = h->K; sd.I = h->I; sd.wd = (float)h->wd; sd.clip = (float)h->clip;
             sd.opt = make_opt_params<float>(h->lr);
-            // whole users per wavefront; every user has about I draws, so equal user counts are equal work
-            const int64_t max_waves = 256 * 12;
+            sd.coherent = !(getenv("CYMF_RELMF_COHERENT_LOADS") && getenv("CYMF_RELMF_COHERENT_LOADS")[0] == '0');
+            // whole users per wavefront; every user has about I draws, so equal user counts are equal work.
+            // Staleness bound, as for the other lock-free launches (hogwild_grid): every wavefront holds up to
+            // RING item rows at a time and the cells are uniform over the I items, so about waves * RING / I
+            // wavefronts hold any one item row at once; their deltas are all computed from the same stale row and
+            // add up, which multiplies the effective step on that row.  Measured: at 17 holders per row (1 500
+            // waves, I = 1 400) a handful of rows ran away (row norms x100) in some runs; at <= 2 none did.
+            const int ring = h->opt == CYMF_OPT_SGD ? 16 : 8;
+            const int holders = getenv("CYMF_RELMF_HOLDERS") ? std::max(1, atoi(getenv("CYMF_RELMF_HOLDERS"))) : 2;
+            const int64_t max_waves = std::max<int64_t>(64, std::min<int64_t>(256 * 12, (int64_t)holders * h->I / ring));
             const int32_t upw = (int32_t)std::max<int64_t>(1, ((int64_t)h->U + max_waves - 1) / max_waves);
             const int64_t waves = ((int64_t)h->U + upw - 1) / upw;
-            launch_relmf_step(h->K, h->opt, sd, h->d_uoff[b].p, h->d_items[b].p, h->U, upw, h->d_loss.p, (int)((waves + 3) / 4), h->stream);
+            CYMF_TRY(h->d_err.alloc(1));
+            CYMF_TRY(h->d_err.zero(h->stream));
+            launch_relmf_step(h->K, h->opt, sd, h->d_uoff[b].p, h->d_items[b].p, h->U, upw, h->d_loss.p, h->d_err.p, (int)((waves + 3) / 4), h->stream);
             CYMF_HIP(hipGetLastError());
             CYMF_HIP(hipEventRecord(h->ev_step_done[b], h->stream));
             h->epoch_cursor++;
@@ -805,8 +830,11 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
         CYMF_HIP(hipGetLastError());
     }
     double loss = 0;
+    int err = 0;
+    if (stepped) CYMF_HIP(hipMemcpyAsync(&err, h->d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     CYMF_HIP(hipMemcpyAsync(&loss, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
+    if (err) return fail(CYMF_ERR_HIP, "relmf: the per-epoch bucketing produced an item index outside [0, I)");
     if (loss_out) *loss_out = loss;
     return 0;
 }
