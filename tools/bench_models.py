@@ -120,3 +120,24 @@ if "exact" in what:
         print(f"BPR exact C2 {opt} f64: {dt*1e3:.1f} ms/epoch ({X.nnz/dt/1e6:.2f} M triplets/s, sequential-order parity mode); "
               f"device {k_ms/5:.1f} ms/epoch in {launches/5:.0f} launches", flush=True)
         t.close()
+
+if "eval" in what:
+    from scipy import sparse
+    from cymf_amd import Evaluator
+    U, I, nnz, K, seed = synthetic.CONFIGS["C4"]
+    rows, cols, indptr = synthetic.implicit_matrix_large(U, I, nnz, seed)
+    X = sparse.csr_matrix((np.ones(len(rows), dtype=np.float32), cols, indptr), shape=(U, I))
+    rs = np.random.RandomState(0)
+    mask = rs.rand(X.nnz) < 0.1
+    Xte = X.copy(); Xte.data = Xte.data * mask; Xte.eliminate_zeros()
+    Xtr = X.copy(); Xtr.data = Xtr.data * (~mask); Xtr.eliminate_zeros()
+    W, H = init(U, I, K)
+    ev = Evaluator(Xte, Xtr)
+    t0 = time.perf_counter()
+    ev.evaluate(W, H)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        r = ev.evaluate(W, H)
+    t2 = time.perf_counter()
+    print(f"Evaluator C4-shaped ({U} users, {Xte.nnz} held-out items, 100 negatives, K={K}): first call {1e3*(t1-t0):.0f} ms "
+          f"(sequential candidate walk included), then {1e3*(t2-t1)/3:.1f} ms per call; {r}", flush=True)
