@@ -61,6 +61,23 @@ def test_exact_mode_c2_shaped_vs_oracle(opt):
     assert rel_fro(m64.H, H) <= 1e-10 and rel_maxabs(m64.H, H) <= 1e-10
 
 
+@pytest.mark.parametrize("opt", ["sgd", "adagrad", "adam"])
+def test_exact_mode_dataflow_and_level_launches_agree(opt, monkeypatch):
+    """The one-launch dataflow execution (bpr_ticket_kernel: per-row turn counters, ordered dispenser) and the
+    one-launch-per-level schedule are two executions of the same sequential order: float64 results agree to
+    rounding of the loss sum only (the rows are bit-identical), also with hot rows (a 30-item catalogue)."""
+    X = synthetic.implicit_matrix(500, 30, 6000, 13)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CYMF_BPR_EXACT_LEVELS", flag)
+        m = _fit(X, 24, opt, 0.02, 0.01, 3, "float64")
+        out.append((m.W.copy(), m.H.copy(), np.array(m.losses)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12)
+    W, H, losses = oracle.bpr_fit(X, 24, opt, 0.02, 0.01, 3)
+    assert rel_fro(out[0][0], W) <= 1e-10 and rel_fro(out[0][1], H) <= 1e-10
+
+
 def _trainer_inputs(X, seed_shuffle=5):
     X = X.tocsr()
     rs = np.random.RandomState(seed_shuffle)
