@@ -69,6 +69,8 @@ def lib():
         "cymf_glove_download": ([vp, vp, vp, vp, vp], ci),
         "cymf_glove_epochs": ([vp, i32, vp], ci),
         "cymf_glove_destroy": ([vp], ci),
+        "cymf_glove_set_steps_per_epoch": ([vp, i32], ci),
+        "cymf_glove_attach_comm": ([vp, vp, vp], ci),
         "cymf_wmf_create": ([pp, i32, i32, i32, f64, f64, ci, ci], ci),
         "cymf_wmf_set_data": ([vp, vp, vp, vp, vp], ci),
         "cymf_wmf_upload": ([vp, vp, vp], ci),

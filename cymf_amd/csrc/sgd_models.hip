@@ -629,6 +629,42 @@ void launch_relmf_step(int K, int opt, const RelStepDev &d, const int64_t *off, 
     else launch_relmf_step_opt<2, false>(opt, d, off, items, U, upw, loss, err, grid, s);
 }
 
+// Multi-GPU GloVe: pairs are sharded by CENTRAL word, the context table is replicated.  After a step
+// every rank forms the deltas of its replica against the last synchronised state -- context rows, their AdaGrad
+// accumulators, {context bias, its accumulator} -- in one buffer that is all-reduced; the accumulators are plain sums
+// of g^2, so their summed deltas ARE the sequential accumulators; rows and biases get the sequentialisation factor
+// of the item-delta exchange of bpr.hip (build_delta_scales there; rho = lr/5 per touch: AdaGrad, no weight decay).
+__global__ void glove_delta_kernel(const float *__restrict__ H, const float *__restrict__ aH, const float2 *__restrict__ b2,
+                                   const float *__restrict__ sH, const float *__restrict__ sA, const float2 *__restrict__ sB,
+                                   float *__restrict__ D, int64_t VK, int64_t V) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < VK; i += stride) {
+        D[i] = H[i] - sH[i];
+        D[VK + i] = aH[i] - sA[i];
+        if (i < V) {
+            D[2 * VK + 2 * i] = b2[i].x - sB[i].x;
+            D[2 * VK + 2 * i + 1] = b2[i].y - sB[i].y;
+        }
+    }
+}
+__global__ void glove_apply_kernel(float *__restrict__ H, float *__restrict__ aH, float2 *__restrict__ b2, float *__restrict__ sH,
+                                   float *__restrict__ sA, float2 *__restrict__ sB, const float *__restrict__ D,
+                                   const float *__restrict__ scale, int K, int64_t VK, int64_t V) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < VK; i += stride) {
+        const float v = sH[i] + scale[i / K] * D[i];
+        H[i] = v; sH[i] = v;
+        const float a = sA[i] + D[VK + i];
+        aH[i] = a; sA[i] = a;
+        if (i < V) {
+            const float2 nb = make_float2(sB[i].x + scale[i] * D[2 * VK + 2 * i], sB[i].y + D[2 * VK + 2 * i + 1]);
+            b2[i] = nb; sB[i] = nb;
+        }
+    }
+}
+
 void launch_glove_step(int K, const GloveStepDev &d, const int32_t *c, const int32_t *x, const float *cnt, int64_t n,
                        int64_t cpw, double *loss, int grid, hipStream_t s) {
 #define CALL_(R_, P_) hipLaunchKernelGGL((glove_step_kernel<R_, P_, 8>), dim3(grid), dim3(256), 0, s, d, c, x, cnt, n, cpw, loss)
@@ -691,6 +727,15 @@ inline int hogwild_grid(int64_t n, double f_max) {
 }  // namespace cymf
 
 using namespace cymf;
+
+struct cymf_comm;
+namespace cymf {
+int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s);   // comm.hip
+int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_t row_bytes, hipStream_t s);
+int comm_world(cymf_comm *c);
+int comm_rank(cymf_comm *c);
+}  // namespace cymf
+
 
 // =====================================================================================
 //                                        RelMF
@@ -971,6 +1016,13 @@ struct cymf_glove {
     std::vector<int64_t> level_off;
     double f_max = 1.0;                     // share of the pairs that touch the most frequent word
     DevBuf<double> d_loss;
+    // multi-GPU: central-word ranges per rank, steps (local windows of the pair order), exchange buffers
+    cymf_comm *comm = nullptr;
+    std::vector<int64_t> central_bounds;
+    int32_t steps_per_epoch = 1;
+    std::vector<int64_t> step_off;
+    DevBuf<float> d_snapH, d_snapA, d_delta, d_scale;
+    DevBuf<float2> d_snapB;
     bool have_data = false, have_params = false;
 };
 
@@ -1000,6 +1052,25 @@ extern "C" int cymf_glove_create(cymf_glove **out, int32_t V, int32_t Vc, int32_
     return 0;
 }
 
+extern "C" int cymf_glove_set_steps_per_epoch(cymf_glove *h, int32_t steps) {
+    if (!h || steps < 1) return fail(CYMF_ERR_INVALID, "cymf_glove_set_steps_per_epoch: bad arguments");
+    if (h->have_data) return fail(CYMF_ERR_INVALID, "cymf_glove_set_steps_per_epoch must precede cymf_glove_set_data");
+    h->steps_per_epoch = steps;
+    return 0;
+}
+
+extern "C" int cymf_glove_attach_comm(cymf_glove *h, cymf_comm *c, const int64_t *central_bounds) {
+    if (!h || !c || !central_bounds) return fail(CYMF_ERR_INVALID, "cymf_glove_attach_comm: bad arguments");
+    if (h->have_data || h->have_params) return fail(CYMF_ERR_INVALID, "cymf_glove_attach_comm must precede cymf_glove_set_data and cymf_glove_upload");
+    const int world = comm_world(c);
+    if (central_bounds[0] != 0 || central_bounds[world] != h->V) return fail(CYMF_ERR_INVALID, "cymf_glove_attach_comm: bounds must run from 0 to V");
+    for (int r = 0; r < world; ++r)
+        if (central_bounds[r] > central_bounds[r + 1]) return fail(CYMF_ERR_INVALID, "cymf_glove_attach_comm: bounds not monotone");
+    h->comm = c;
+    h->central_bounds.assign(central_bounds, central_bounds + world + 1);
+    return 0;
+}
+
 extern "C" int cymf_glove_set_data(cymf_glove *h, const int32_t *central, const int32_t *context, const double *counts,
                                    int64_t N) {
     if (!h || N < 0 || (N > 0 && (!central || !context || !counts))) return fail(CYMF_ERR_INVALID, "cymf_glove_set_data: bad arguments");
@@ -1025,23 +1096,61 @@ extern "C" int cymf_glove_set_data(cymf_glove *h, const int32_t *central, const 
         level_schedule(N, central, context, h->V, h->Vc, order, h->level_off);
         for (int64_t p = 0; p < N; ++p) { c[p] = central[order[p]]; x[p] = context[order[p]]; cnt[p] = counts[order[p]]; }
     }
+    const int32_t S = h->step_path ? std::max(1, h->steps_per_epoch) : 1;
+    h->step_off.assign((size_t)S + 1, 0);
+    h->step_off[S] = N;
+    if (h->comm) {
+        if (!h->step_path) return fail(CYMF_ERR_UNSUPPORTED, "cymf_glove: a communicator needs the float32 throughput step path (K <= 128)");
+        const int64_t lo = h->central_bounds[comm_rank(h->comm)], hi = h->central_bounds[comm_rank(h->comm) + 1];
+        for (int64_t s = 0; s < N; ++s)
+            if (central[s] < lo || central[s] >= hi)
+                return fail(CYMF_ERR_INVALID, "cymf_glove_set_data: pair %lld has central word %d outside this rank's range [%lld, %lld)",
+                            (long long)s, central[s], (long long)lo, (long long)hi);
+    }
     if (h->step_path && N > 0) {
-        // central-bucketed order (stable) + hot context words: a word that is the context of at least
-        // HOT pairs is updated with atomic deltas by the step kernel; the number of wavefronts keeps the
-        // expected number of waves inside a COLD row's read-modify-write window at <= 2
-        std::vector<int64_t> nc((size_t)h->V + 1, 0), nx((size_t)h->Vc, 0);
-        for (int64_t s = 0; s < N; ++s) { nc[(size_t)central[s] + 1]++; nx[context[s]]++; }
-        for (int32_t v = 0; v < h->V; ++v) nc[v + 1] += nc[v];
+        // (step, central)-bucketed order (stable): step = window of the given order; hot context words: a word that
+        // is the context of at least HOT pairs is updated with atomic deltas by the step kernel; the number of
+        // wavefronts keeps the expected number of waves inside a COLD row's read-modify-write window at <= 2
+        auto step_of = [&](int64_t l) -> int32_t { return (int32_t)(((__int128)l * S) / N); };
+        std::fill(h->step_off.begin(), h->step_off.end(), 0);
+        std::vector<int64_t> nx((size_t)h->Vc, 0);
+        for (int64_t s = 0; s < N; ++s) nx[context[s]]++;
+        for (int64_t l = 0; l < N; ++l) h->step_off[(size_t)step_of(l) + 1]++;
+        h->step_off[0] = 0;
+        for (int32_t q = 0; q < S; ++q) h->step_off[q + 1] += h->step_off[q];
         const int64_t HOT = 4096;
-        std::vector<int64_t> cur(nc.begin(), nc.end() - 1);
-        for (int64_t s = 0; s < N; ++s) {
-            const int64_t p = cur[central[s]]++;
-            c[p] = central[s];
-            x[p] = context[s] | (nx[context[s]] >= HOT ? (1 << 30) : 0);
-            cnt[p] = counts[s];
+        std::vector<int64_t> nc((size_t)h->V + 1);
+        for (int32_t q = 0; q < S; ++q) {
+            const int64_t b = h->step_off[q], e = h->step_off[q + 1];   // the window is [b, e) of the given order too
+            std::fill(nc.begin(), nc.end(), 0);
+            for (int64_t l = b; l < e; ++l) nc[(size_t)central[l] + 1]++;
+            for (int32_t v = 0; v < h->V; ++v) nc[v + 1] += nc[v];
+            for (int64_t l = b; l < e; ++l) {
+                const int64_t p = b + nc[central[l]]++;
+                c[p] = central[l];
+                x[p] = context[l] | (nx[context[l]] >= HOT ? (1 << 30) : 0);
+                cnt[p] = counts[l];
+            }
         }
         const double f_cold = (double)std::min<int64_t>(HOT, N) / (double)N;
         h->step_waves = std::max<int64_t>(1, std::min<int64_t>((int64_t)(2.0 / (f_cold * 8)), 256 * 8));
+    }
+    if (h->comm) {   // sequentialisation factors per step and context word (see build_delta_scales in bpr.hip)
+        const int world = comm_world(h->comm);
+        std::vector<float> cntx((size_t)S * h->V, 0.0f);
+        for (int32_t q = 0; q < S; ++q)
+            for (int64_t l = h->step_off[q]; l < h->step_off[q + 1]; ++l) cntx[(size_t)q * h->V + context[l]] += 1.0f;
+        DevBuf<float> dtmp;
+        CYMF_TRY(dtmp.upload(cntx.data(), cntx.size(), h->stream));
+        CYMF_TRY(comm_allreduce_sum_f32(h->comm, dtmp.p, (int64_t)cntx.size(), h->stream));
+        CYMF_HIP(hipMemcpyAsync(cntx.data(), dtmp.p, cntx.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+        const double base = 1.0 - std::min(0.5, 0.2 * h->lr);
+        for (float &v : cntx) {
+            const double a = std::pow(base, (double)v / world);
+            v = (float)(a < 1.0 - 1e-12 ? (1.0 - std::pow(a, world)) / (world * (1.0 - a)) : 1.0);
+        }
+        CYMF_TRY(h->d_scale.upload(cntx.data(), cntx.size(), h->stream));
     }
     CYMF_TRY(h->d_central.upload(c.data(), c.size(), h->stream));
     CYMF_TRY(h->d_context.upload(x.data(), x.size(), h->stream));
@@ -1080,6 +1189,16 @@ extern "C" int cymf_glove_upload(cymf_glove *h, const double *W, const double *b
         CYMF_HIP(hipGetLastError());
         CYMF_HIP(hipStreamSynchronize(h->stream));
     }
+    if (h->comm) {   // the state every rank starts from is the synchronised one
+        const size_t VK = (size_t)h->V * h->K;
+        if ((size_t)h->Vc != (size_t)h->V) return fail(CYMF_ERR_UNSUPPORTED, "cymf_glove: multi-GPU needs a square co-occurrence matrix (V == Vc)");
+        CYMF_TRY(h->d_snapH.alloc(VK)); CYMF_TRY(h->d_snapA.alloc(VK)); CYMF_TRY(h->d_snapB.alloc((size_t)h->V));
+        CYMF_TRY(h->d_delta.alloc(2 * VK + 2 * (size_t)h->V));
+        CYMF_HIP(hipMemcpyAsync(h->d_snapH.p, h->f32.H.p, VK * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        CYMF_HIP(hipMemcpyAsync(h->d_snapA.p, h->f32.aH.p, VK * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        CYMF_HIP(hipMemcpyAsync(h->d_snapB.p, h->bH2.p, (size_t)h->V * sizeof(float2), hipMemcpyDeviceToDevice, h->stream));
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+    }
     h->have_params = true;
     return 0;
 }
@@ -1088,6 +1207,10 @@ extern "C" int cymf_glove_download(cymf_glove *h, double *W, double *bias, doubl
     if (!h || !W || !bias || !Wc || !bias_c || !h->have_params) return fail(CYMF_ERR_INVALID, "cymf_glove_download: bad arguments / no params");
     CYMF_TRY(use_device(h->device));
     const size_t nW = (size_t)h->V * h->K, nH = (size_t)h->Vc * h->K;
+    if (h->comm) {   // every rank ends with all central rows and biases (its own range was trained here)
+        CYMF_TRY(comm_allgatherv(h->comm, h->f32.W.p, h->central_bounds.data(), (int64_t)h->K * (int64_t)sizeof(float), h->stream));
+        CYMF_TRY(comm_allgatherv(h->comm, h->bW2.p, h->central_bounds.data(), (int64_t)sizeof(float2), h->stream));
+    }
     if (h->step_path) {
         hipLaunchKernelGGL(unpack2_kernel, dim3(ew_blocks(h->V)), dim3(256), 0, h->stream, h->bW2.p, h->f32.bW.p, h->f32.abW.p, (int64_t)h->V);
         hipLaunchKernelGGL(unpack2_kernel, dim3(ew_blocks(h->V)), dim3(256), 0, h->stream, h->bH2.p, h->f32.bH.p, h->f32.abH.p, (int64_t)h->V);
@@ -1118,12 +1241,29 @@ static int glove_epoch(cymf_glove *h, GloveStore<T> &st, double *loss_out) {
                 r.aW = reinterpret_cast<float *>(st.aW.p); r.aH = reinterpret_cast<float *>(st.aH.p);
                 r.bW2 = h->bW2.p; r.bH2 = h->bH2.p;
                 r.K = h->K; r.lr = (float)h->lr; r.x_max = (float)h->x_max; r.alpha = (float)h->alpha;
-                const int64_t chunks = (h->N + 63) / 64;
-                int64_t waves = std::max<int64_t>(1, std::min(chunks, h->step_waves));
-                const int64_t cpw = (chunks + waves - 1) / waves;
-                waves = (chunks + cpw - 1) / cpw;
-                launch_glove_step(h->K, r, h->d_central.p, h->d_context.p, reinterpret_cast<const float *>(st.counts.p), h->N, cpw,
-                                  h->d_loss.p, (int)((waves + 3) / 4), h->stream);
+                const int32_t S = (int32_t)h->step_off.size() - 1;
+                for (int32_t q = 0; q < S; ++q) {
+                    const int64_t b = h->step_off[q], n = h->step_off[q + 1] - b;
+                    if (n > 0) {
+                        const int64_t chunks = (n + 63) / 64;
+                        int64_t waves = std::max<int64_t>(1, std::min(chunks, h->step_waves));
+                        const int64_t cpw = (chunks + waves - 1) / waves;
+                        waves = (chunks + cpw - 1) / cpw;
+                        launch_glove_step(h->K, r, h->d_central.p + b, h->d_context.p + b, reinterpret_cast<const float *>(st.counts.p) + b, n,
+                                          cpw, h->d_loss.p, (int)((waves + 3) / 4), h->stream);
+                        CYMF_HIP(hipGetLastError());
+                    }
+                    if (h->comm) {   // every rank takes part in every step's exchange, with or without pairs of its own
+                        const int64_t VK = (int64_t)h->V * h->K, V = h->V;
+                        hipLaunchKernelGGL(glove_delta_kernel, dim3(ew_blocks(VK)), dim3(256), 0, h->stream, r.H, r.aH, r.bH2, h->d_snapH.p,
+                                           h->d_snapA.p, h->d_snapB.p, h->d_delta.p, VK, V);
+                        CYMF_HIP(hipGetLastError());
+                        CYMF_TRY(comm_allreduce_sum_f32(h->comm, h->d_delta.p, 2 * VK + 2 * V, h->stream));
+                        hipLaunchKernelGGL(glove_apply_kernel, dim3(ew_blocks(VK)), dim3(256), 0, h->stream, r.H, r.aH, r.bH2, h->d_snapH.p,
+                                           h->d_snapA.p, h->d_snapB.p, h->d_delta.p, h->d_scale.p + (size_t)q * h->V, h->K, VK, V);
+                        CYMF_HIP(hipGetLastError());
+                    }
+                }
             }
         } else if (h->mode == CYMF_MODE_THROUGHPUT) {
             launch_glove<T>(h->K, d, h->d_central.p, h->d_context.p, st.counts.p, h->N, h->d_loss.p, hogwild_grid(h->N, h->f_max), h->stream);

@@ -44,6 +44,15 @@ def step_of(global_pos, steps_per_epoch, n_global):
     return (np.asarray(global_pos, dtype=np.int64) * int(steps_per_epoch)) // max(int(n_global), 1)
 
 
+def word_bounds(central, n_words, world):
+    """Contiguous central-word ranges with about equal numbers of pairs: bounds[r] .. bounds[r+1] is rank r's
+    (GloVe sharding).  Returns an int64 array of world + 1 entries from 0 to n_words."""
+    counts = np.bincount(np.asarray(central, dtype=np.int64), minlength=n_words)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    bounds = np.searchsorted(cum, cum[-1] * np.arange(1, world) / world, side="left")
+    return np.concatenate([[0], np.minimum(bounds, n_words), [n_words]]).astype(np.int64)
+
+
 def delta_rho(optimizer, lr, wd):
     """Per-touch contraction assumed for a replica of an item row (host mirror of build_delta_scales, csrc/bpr.hip)."""
     rho = 2.0 * lr * wd

@@ -21,9 +21,12 @@ class GloVe(object):
         self.x_max = float(x_max)
         self.W = None
 
-    def fit(self, X, num_epochs, num_threads, verbose=False, *, mode=None, dtype=None, device=0):
+    def fit(self, X, num_epochs, num_threads, verbose=False, *, mode=None, dtype=None, device=0, comm=None, steps_per_epoch=1):
         """cymf/glove.pyx:75-112.  No seeding here either: initial factors come from the caller's
-        global numpy state (glove.pyx:91-94)."""
+        global numpy state (glove.pyx:91-94).
+        comm (a dist.Comm, one process per GPU, throughput mode): every rank passes the same X and the same numpy
+        state; the pairs are sharded by central word, the context table is replicated and synchronised after each
+        of the steps_per_epoch steps; every rank ends with the same full tables."""
         if X is None:
             raise ValueError()
         if not isinstance(X, (sparse.lil_matrix, sparse.csr_matrix, sparse.csc_matrix)):
@@ -38,17 +41,28 @@ class GloVe(object):
         central_words, context_words, counts = _host.reference_shuffle(central_words, context_words, counts)
         mode = _host.pick_mode(mode, num_threads)
         dtype = _host.pick_dtype(dtype, mode)
+        bounds = None
+        n_all = len(counts)
+        if comm is not None:
+            from . import dist
+            bounds = dist.word_bounds(central_words, X.shape[0], comm.world)
+            mine = (central_words >= bounds[comm.rank]) & (central_words < bounds[comm.rank + 1])
+            central_words, context_words, counts = central_words[mine], context_words[mine], counts[mine]
+            device = comm.device
         trainer = GloveTrainer(X.shape[0], X.shape[1], K, self.learning_rate, self.x_max, self.alpha,
-                               dtype=dtype, mode=mode, device=device)
+                               dtype=dtype, mode=mode, device=device, comm=comm, central_bounds=bounds,
+                               steps_per_epoch=steps_per_epoch)
         try:
             trainer.set_data(central_words, context_words, counts)
             trainer.upload(self.W, self.bias, _W, _bias)
             bar = _host.Progress(num_epochs, verbose, ncols=100)
             width = len(str(num_epochs))
-            n = max(len(counts), 1)
+            n = max(n_all, 1)
             self.losses = []
             for it in range(num_epochs):
                 loss = trainer.epochs(1)[0]
+                if comm is not None:   # the loss of the whole job
+                    loss = float(comm.allreduce(np.array([loss], dtype=np.float32))[0])
                 self.losses.append(loss / n)
                 bar.step(f"ITER={it+1:{width}}, LOSS: {np.round(loss / n, 4):.4f}")   # glove.pyx:158-162
             bar.close()
@@ -101,12 +115,21 @@ def read_text(fname, min_count=5, window_size=10):
 
 
 class GloveTrainer:
-    def __init__(self, V, Vc, K, lr=0.01, x_max=10.0, alpha=0.75, dtype="float32", mode="exact", device=0):
+    def __init__(self, V, Vc, K, lr=0.01, x_max=10.0, alpha=0.75, dtype="float32", mode="exact", device=0,
+                 comm=None, central_bounds=None, steps_per_epoch=1):
         self.L = _lib.lib()
         self.V, self.Vc, self.K = int(V), int(Vc), int(K)
         self.h = C.c_void_p()
         _lib.check(self.L.cymf_glove_create(C.byref(self.h), self.V, self.Vc, self.K, lr, x_max, alpha,
                                             _lib.DTYPE_IDS[dtype], _lib.MODE_IDS[mode], device))
+        self.comm = comm
+        if steps_per_epoch != 1:
+            _lib.check(self.L.cymf_glove_set_steps_per_epoch(self.h, int(steps_per_epoch)))
+        if comm is not None:
+            b = np.ascontiguousarray(central_bounds, dtype=np.int64)
+            if len(b) != comm.world + 1:
+                raise ValueError("central_bounds must have world + 1 entries")
+            _lib.check(self.L.cymf_glove_attach_comm(self.h, comm.h, _lib.ptr(b)))
 
     def set_data(self, central, context, counts):
         c, x, n = _lib.i32c(central), _lib.i32c(context), _lib.f64c(counts)

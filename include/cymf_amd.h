@@ -151,6 +151,13 @@ int cymf_glove_upload(cymf_glove *h, const double *W, const double *bias, const 
 int cymf_glove_download(cymf_glove *h, double *W, double *bias, double *Wc, double *bias_c);
 int cymf_glove_epochs(cymf_glove *h, int32_t n_epochs, double *loss_out);   /* loss_out[e] = sum of loss[l], :155-156 */
 int cymf_glove_destroy(cymf_glove *h);
+/* Multi-GPU (no counterpart in the reference): pairs are sharded by central word -- rank r passes only the pairs whose
+ * central word lies in [central_bounds[r], central_bounds[r+1]) -- the context table is replicated and its deltas
+ * (rows, AdaGrad accumulators, bias pairs) are all-reduced after each of the steps_per_epoch steps (windows of the
+ * rank's pair order); download() gathers the central rows, so every rank returns the full tables.  float32
+ * throughput mode, V == Vc.  Both calls precede cymf_glove_set_data. */
+int cymf_glove_set_steps_per_epoch(cymf_glove *h, int32_t steps);
+int cymf_glove_attach_comm(cymf_glove *h, cymf_comm *c, const int64_t *central_bounds);
 
 /* ---------------------------------------------------------------- WMF
  * replaces WMF._als, cymf/wmf.pyx:136-174 (Gramian :142-143, per-row accumulate :161-166)

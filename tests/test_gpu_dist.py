@@ -93,3 +93,23 @@ def test_wmf_with_world1_communicator_equals_plain_fit():
     b.fit(X, num_epochs=2, verbose=False, comm=comm)
     assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H)
     comm.close()
+
+
+def test_glove_with_world1_communicator_and_steps():
+    """GloVe sharding machinery at world size 1: the whole vocabulary is one range, the all-reduce is the identity
+    and H = snapshot + (H - snapshot) reproduces the plain fit up to float rounding; several steps per epoch
+    (another bucketing of the same pairs) train to the same loss level."""
+    from cymf_amd import GloVe
+    comm = dist.Comm(0, 1, 0, dist.Comm.unique_id())
+    X = synthetic.cooccurrence_matrix(800, 60000, 64)
+    fits = {}
+    for name, kw in (("plain", {}), ("comm", dict(comm=comm)), ("comm3", dict(comm=comm, steps_per_epoch=3)), ("steps3", dict(steps_per_epoch=3))):
+        np.random.seed(5)
+        m = GloVe(32, 0.05)
+        m.fit(X, 3, 0, **kw)
+        fits[name] = (m.W.copy(), np.array(m.losses))
+    np.testing.assert_allclose(fits["comm"][1], fits["plain"][1], rtol=2e-3)
+    assert abs(np.linalg.norm(fits["comm"][0]) / np.linalg.norm(fits["plain"][0]) - 1) < 1e-2
+    np.testing.assert_allclose(fits["comm3"][1], fits["steps3"][1], rtol=2e-3)
+    np.testing.assert_allclose(fits["steps3"][1][-1], fits["plain"][1][-1], rtol=5e-2)
+    comm.close()

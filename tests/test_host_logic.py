@@ -188,3 +188,16 @@ def test_movielens_local_loader(tmp_path):
         want[u, i] = r
     assert (ds.train.tocsr() != want.tocsr()).nnz == 0
     assert sorted(zip(te.user, te.item)) == sorted(zip(*ds.test.nonzero()))
+
+
+def test_word_bounds_balance_pairs():
+    rs = np.random.RandomState(0)
+    central = rs.zipf(1.3, 200000) % 5000
+    for world in (1, 2, 3, 8):
+        b = dist.word_bounds(central, 5000, world)
+        assert b[0] == 0 and b[-1] == 5000 and len(b) == world + 1 and (np.diff(b) >= 0).all()
+        per = [np.sum((central >= b[r]) & (central < b[r + 1])) for r in range(world)]
+        assert sum(per) == len(central)
+        if world > 1:
+            heaviest = np.bincount(central).max()
+            assert max(per) <= len(central) / world + heaviest       # off by at most the word on the boundary
