@@ -71,6 +71,7 @@ template <typename T>
 struct OptParams {
     T lr;
     T b1, b2, omb1, omb2, eps;   // Adam: beta1, beta2, (1-beta1), (1-beta2), epsilon
+    T inv_omb1, inv_omb2;        // reciprocals, for the lock-free kernels
 };
 
 template <typename T>
@@ -82,6 +83,8 @@ inline OptParams<T> make_opt_params(double lr) {
     p.omb1 = (T)(1 - 0.9);
     p.omb2 = (T)(1 - 0.999);
     p.eps = (T)1e-8;
+    p.inv_omb1 = (T)(1.0 / (1 - 0.9));
+    p.inv_omb2 = (T)(1.0 / (1 - 0.999));
     return p;
 }
 
@@ -98,7 +101,8 @@ __device__ __forceinline__ void opt_update(const OptParams<T> &o, T &p, T &s0, T
         p -= o.lr * g;
     } else if constexpr (OPT == CYMF_OPT_ADAGRAD) {
         s0 += g * g;
-        p -= o.lr * g / fsqrt(s0);
+        if constexpr (HOG && sizeof(T) == 4) p -= o.lr * g * __frsqrt_rn(s0);   // lock-free kernels: v_rsq_f32 instead of sqrt + IEEE division
+        else p -= o.lr * g / fsqrt(s0);
     } else {
         if constexpr (HOG) s1 = s1 < T(0) ? T(0) : s1;
         s0 = o.b1 * s0 + o.omb1 * g;
@@ -108,7 +112,8 @@ __device__ __forceinline__ void opt_update(const OptParams<T> &o, T &p, T &s0, T
             const T bound = s0 * s0 * (o.omb2 * (T(1) - o.b1 * o.b1 / o.b2) / (o.omb1 * o.omb1));
             v = v < bound ? bound : v;
         }
-        p -= o.lr * (s0 / o.omb1) / (fsqrt(v / o.omb2) + o.eps);
+        if constexpr (HOG && sizeof(T) == 4) p -= o.lr * (s0 * o.inv_omb1) * __frcp_rn(fsqrt(v * o.inv_omb2) + o.eps);
+        else p -= o.lr * (s0 / o.omb1) / (fsqrt(v / o.omb2) + o.eps);
     }
 }
 

@@ -319,14 +319,14 @@ __global__ __launch_bounds__(256) void glove_step_kernel(GloveStepDev d, const i
                     for (int r = 0; r < R; ++r) {
                         const int k = RowT::kof(lane, r);
                         if (k < K) {   // lanes past K hold zeros (also in the accumulators): keep 0/sqrt(0) out of w
-                            pbw += 1.0f / fsqrt(bw.y + (float)(k + 1) * g2);
-                            pbh += 1.0f / fsqrt(bhq[e].y + (float)(k + 1) * g2);
+                            pbw += __frsqrt_rn(bw.y + (float)(k + 1) * g2);     // v_rsq_f32: the step kernel is VALU-heavy (4 roots and
+                            pbh += __frsqrt_rn(bhq[e].y + (float)(k + 1) * g2); // 4 divisions per element and pair with sqrt + div)
                             const float wv = w.v[r], hv = hq[e].v[r];
                             const float gw = diff * hv, gh = diff * wv;
                             aw.v[r] += gw * gw;
-                            w.v[r] -= d.lr * gw / fsqrt(aw.v[r]);
+                            w.v[r] -= d.lr * gw * __frsqrt_rn(aw.v[r]);
                             ahq[e].v[r] += gh * gh;
-                            hq[e].v[r] -= d.lr * gh / fsqrt(ahq[e].v[r]);
+                            hq[e].v[r] -= d.lr * gh * __frsqrt_rn(ahq[e].v[r]);
                         }
                     }
                     const float sbw = wave_sum(pbw), sbh = wave_sum(pbh);
