@@ -80,6 +80,12 @@ def lib():
         "cymf_wmf_destroy": ([vp], ci),
         "cymf_wmf_attach_comm": ([vp, vp], ci),
         "cymf_wmf_row_range": ([vp, ci, vp, vp], ci),
+        "cymf_expomf_create": ([pp, i32, i32, i32, f64, f64, ci], ci),
+        "cymf_expomf_set_data": ([vp, vp, vp, vp, vp], ci),
+        "cymf_expomf_upload": ([vp, vp, vp], ci),
+        "cymf_expomf_download": ([vp, vp, vp], ci),
+        "cymf_expomf_epochs": ([vp, i32], ci),
+        "cymf_expomf_destroy": ([vp], ci),
         "cymf_eval_create": ([pp, i32, i32, vp, vp, vp, vp, vp, i32, ci], ci),
         "cymf_eval_num_users": ([vp, vp], ci),
         "cymf_eval_negatives": ([vp, u32, i32, vp, vp, vp], ci),

@@ -207,6 +207,20 @@ int cymf_eval_run(cymf_eval *h, const double *W, const double *H, int32_t K, uin
                   int unbiased, double *out);
 int cymf_eval_destroy(cymf_eval *h);
 
+/* ---------------------------------------------------------------- ExpoMF
+ * replaces ExpoMF._fit_als / _als, cymf/expomf.pyx:105-207: per epoch the dense exposure E-step (:141-144), the
+ * user and item solves with the exposure-weighted Gramian over ALL columns (:163-204, solvep = dgesv), and the
+ * update of the exposure priors mu (:149).  float64; CSR patterns of X and of its transpose as for WMF. */
+typedef struct cymf_expomf cymf_expomf;
+int cymf_expomf_create(cymf_expomf **out, int32_t U, int32_t I, int32_t K, double lam_y, double weight_decay,
+                       int device);
+int cymf_expomf_set_data(cymf_expomf *h, const int32_t *indptr, const int32_t *indices,
+                         const int32_t *t_indptr, const int32_t *t_indices);
+int cymf_expomf_upload(cymf_expomf *h, const double *W, const double *H);
+int cymf_expomf_download(cymf_expomf *h, double *W, double *H);
+int cymf_expomf_epochs(cymf_expomf *h, int32_t n_epochs);
+int cymf_expomf_destroy(cymf_expomf *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -253,3 +253,38 @@ def bpr_fit(Xcsr, K, optimizer, lr, wd, num_epochs, W=None, H=None):
     losses = [m.epoch(users, positives, pat.indptr, pat.indices) for _ in range(num_epochs)]
     m.close()
     return W, H, losses
+
+
+# --------------------------------------------------------------------------- ExpoMF (numpy restatement)
+def expomf_fit(Xcsr, W, H, num_epochs, lam_y=1.0, weight_decay=0.01):
+    """cymf/expomf.pyx:105-207 in numpy, in place on W and H: E-step (:141-144, with the reference's
+    sqrt(lam_y / 2.0 * pi)), user solves, item solves with the updated W (:146-147, np.linalg.solve is
+    the dgesv of solvep), mu (:149).  PARITY UNPINNED: expomf.pyx does not build here (cblas)."""
+    from scipy import sparse
+    X = sparse.csr_matrix(Xcsr).astype(np.float64)
+    X.eliminate_zeros()
+    U, I = X.shape
+    K = W.shape[1]
+    mu = np.ones(I) * 0.01
+    rows, cols = X.nonzero()
+
+    def als(P, E, Xf, Yf):
+        ridge = (weight_decay / lam_y) * np.eye(K)
+        for i in range(P.shape[0]):
+            idx = P.indices[P.indptr[i]:P.indptr[i + 1]]
+            if len(idx) == 0:
+                Xf[i] = 0.0
+                continue
+            b = (Yf[idx] * (E[i, idx] * lam_y)[:, None]).sum(axis=0)
+            A = ridge + (Yf * (E[i] * lam_y)[:, None]).T @ Yf
+            Xf[i] = np.linalg.solve(A, b)
+
+    Xt = X.T.tocsr()
+    for _ in range(num_epochs):
+        n_ui = np.sqrt(lam_y / 2.0 * np.pi) * np.exp(-lam_y * np.dot(W, H.T) ** 2 / 2.0)
+        E = (n_ui + 1e-8) / (n_ui + 1e-8 + (1 - mu) / mu)
+        E[rows, cols] = 1.0
+        als(X, E, W, H)
+        als(Xt, E.T, H, W)
+        mu = (1.0 + E.sum(axis=0) - 1.0) / (1.0 + 1.0 + U - 2.0)
+    return mu
