@@ -507,6 +507,27 @@ __global__ void delta_kernel(const float *__restrict__ H, const float *__restric
     for (; i < n; i += stride) delta[i] = H[i] - snap[i];
 }
 // scale[row]: the sequentialisation factor of that item for this step (see build_delta_scales)
+// overlapped exchange: `base` is the state every rank agrees on bit for bit (all damped sums applied so far); the
+// live table is base + this rank's delta of the step whose exchange is still in flight.  When the sum of the
+// previous step arrives: base += s * sum, H = base + (delta of the step just computed), reference point = H.
+__global__ void correct_delta_kernel(float *__restrict__ H, float *__restrict__ snap, float *__restrict__ base,
+                                     const float *__restrict__ glob, const float *__restrict__ local_cur,
+                                     const float *__restrict__ scale, int K, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float bnew = base[i] + scale[i / K] * glob[i];
+        const float v = local_cur ? bnew + local_cur[i] : bnew;
+        base[i] = bnew;
+        H[i] = v;
+        snap[i] = v;
+    }
+}
+__global__ void snapshot_kernel(const float *__restrict__ H, float *__restrict__ snap, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) snap[i] = H[i];
+}
 __global__ void apply_delta_kernel(float *__restrict__ H, float *__restrict__ snap, const float *__restrict__ delta,
                                    const float *__restrict__ scale, int K, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -666,6 +687,15 @@ struct cymf_bpr {
     // multi-GPU
     cymf_comm *comm = nullptr;
     DevBuf<float> d_snap, d_delta;
+    // overlapped exchange (default): the all-reduce of step s runs on comm_stream under the step kernel of step s+1
+    bool overlap_exchange = true;   // CYMF_BPR_SYNC_EXCHANGE=1: exchange and apply before the next step instead
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_delta_ready = nullptr, ev_reduced[2] = {nullptr, nullptr};
+    DevBuf<float> d_local[2], d_glob[2], d_base;
+    bool exch_pending = false;
+    int exch_parity = 0;
+    int64_t exch_count = 0;
+    const float *exch_scale = nullptr;
     DevBuf<float> d_delta_scale;        // [steps_per_epoch][I] sequentialisation factors of the summed deltas
 
     // profiling of the dominant kernel
@@ -678,6 +708,7 @@ struct cymf_bpr {
 
 namespace cymf {
 int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s);   // comm.hip
+int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, hipStream_t s);
 int comm_world(cymf_comm *c);
 }
 
@@ -793,6 +824,25 @@ bool csr_has(const std::vector<int32_t> &indptr, const std::vector<int32_t> &ind
 }
 
 // ---- negatives of epoch `e` into d_draws[e & 1]; generated in stream order on rng_stream
+// overlapped exchange: wait for the all-reduce in flight (if any) and apply it (correct_delta_kernel); local_cur is
+// the delta of the step just computed (nullptr when flushing: then H ends equal to the common base on every rank).
+// With nothing in flight the reference point is simply refreshed (snapshot_if_idle).
+int finish_exchange(cymf_bpr *h, bool snapshot_if_idle, const float *local_cur = nullptr) {
+    const int64_t n = (int64_t)h->I * h->K;
+    if (h->exch_pending) {
+        const int pb = h->exch_parity;
+        CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_reduced[pb], 0));
+        hipLaunchKernelGGL(correct_delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_base.p,
+                           h->d_glob[pb].p, local_cur, h->exch_scale, h->K, n);
+        CYMF_HIP(hipGetLastError());
+        h->exch_pending = false;
+    } else if (snapshot_if_idle) {
+        hipLaunchKernelGGL(snapshot_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, n);
+        CYMF_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 int request_epoch_draws(cymf_bpr *h, int64_t e) {
     while (h->epochs_generated <= e) {
         const int64_t g = h->epochs_generated;
@@ -1067,7 +1117,24 @@ int run_one_step(cymf_bpr *h) {
         }
         h->slots_done += e - b;
     }
-    if (h->comm) {   // sum of the ranks' item-factor deltas
+    if (h->comm && h->overlap_exchange) {
+        // delta of this step against the reference point; the exchange of the PREVIOUS step has had this step's
+        // kernel to finish: its damped sum replaces the local delta that H already carries; then this step's
+        // delta goes out on the communication stream while the next step computes
+        const int64_t n = (int64_t)h->I * h->K;
+        const int b = (int)(h->exch_count & 1);
+        hipLaunchKernelGGL(delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_local[b].p, n);
+        CYMF_HIP(hipGetLastError());
+        CYMF_TRY(finish_exchange(h, /*snapshot_if_idle=*/true, h->d_local[b].p));
+        CYMF_HIP(hipEventRecord(h->ev_delta_ready, h->stream));
+        CYMF_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_delta_ready, 0));
+        CYMF_TRY(comm_allreduce_sum_f32_to(h->comm, h->d_local[b].p, h->d_glob[b].p, n, h->comm_stream));
+        CYMF_HIP(hipEventRecord(h->ev_reduced[b], h->comm_stream));
+        h->exch_pending = true;
+        h->exch_parity = b;
+        h->exch_scale = h->d_delta_scale.p + (size_t)s * h->I;
+        h->exch_count++;
+    } else if (h->comm) {   // sum of the ranks' item-factor deltas
         const int64_t n = (int64_t)h->I * h->K;
         hipLaunchKernelGGL(delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_delta.p, n);
         CYMF_HIP(hipGetLastError());
@@ -1373,8 +1440,16 @@ extern "C" int cymf_bpr_upload(cymf_bpr *h, const double *W, const double *H) {
     else CYMF_TRY(upload_store(h, h->f64, W, H));
     if (h->comm) {
         const size_t n = (size_t)h->I * h->K;
+        if (h->comm_stream) CYMF_HIP(hipStreamSynchronize(h->comm_stream));   // (a re-upload drops an exchange in flight)
         CYMF_TRY(h->d_snap.alloc(n));
-        CYMF_TRY(h->d_delta.alloc(n));
+        if (h->overlap_exchange) {
+            for (int b = 0; b < 2; ++b) { CYMF_TRY(h->d_local[b].alloc(n)); CYMF_TRY(h->d_glob[b].alloc(n)); }
+            CYMF_TRY(h->d_base.alloc(n));
+            CYMF_HIP(hipMemcpyAsync(h->d_base.p, h->f32.H.p, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            h->exch_pending = false;
+        } else {
+            CYMF_TRY(h->d_delta.alloc(n));
+        }
         CYMF_HIP(hipMemcpyAsync(h->d_snap.p, h->f32.H.p, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         CYMF_HIP(hipStreamSynchronize(h->stream));
     }
@@ -1386,6 +1461,7 @@ extern "C" int cymf_bpr_download(cymf_bpr *h, double *W, double *H) {
     if (!h || !W || !H) return fail(CYMF_ERR_INVALID, "cymf_bpr_download: bad arguments");
     if (!h->have_params) return fail(CYMF_ERR_INVALID, "cymf_bpr_download before cymf_bpr_upload");
     CYMF_TRY(use_device(h->device));
+    if (h->comm && h->overlap_exchange) CYMF_TRY(finish_exchange(h, false));   // the last step's exchange is still in flight
     CYMF_HIP(hipStreamSynchronize(h->stream));
     const size_t nW = (size_t)h->U * h->K, nH = (size_t)h->I * h->K;
     if (h->dtype == CYMF_F32) { CYMF_TRY(download_f64(h->f32.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f32.H, H, nH, h->stream)); }
@@ -1429,6 +1505,7 @@ extern "C" int cymf_bpr_epochs(cymf_bpr *h, int32_t n_epochs, double *loss_out) 
 extern "C" int cymf_bpr_sync(cymf_bpr *h) {
     if (!h) return fail(CYMF_ERR_INVALID, "cymf_bpr_sync: NULL handle");
     CYMF_TRY(use_device(h->device));
+    if (h->comm && h->overlap_exchange && h->have_params) CYMF_TRY(finish_exchange(h, false));
     CYMF_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1484,6 +1561,13 @@ extern "C" int cymf_bpr_attach_comm(cymf_bpr *h, cymf_comm *c) {
     if (h->mode != CYMF_MODE_THROUGHPUT) return fail(CYMF_ERR_UNSUPPORTED, "a communicator needs throughput mode");
     if (h->have_params || h->have_data) return fail(CYMF_ERR_INVALID, "cymf_bpr_attach_comm must precede cymf_bpr_set_data and cymf_bpr_upload");
     h->comm = c;
+    if (const char *e = getenv("CYMF_BPR_SYNC_EXCHANGE")) h->overlap_exchange = !(e[0] == '1');
+    if (h->overlap_exchange && !h->comm_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta_ready, hipEventDisableTiming);
+        for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&h->ev_reduced[b], hipEventDisableTiming);
+        if (e != hipSuccess) return fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
     return 0;
 }
 
@@ -1499,6 +1583,9 @@ extern "C" int cymf_bpr_destroy(cymf_bpr *h) {
         if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
         if (h->ev_epoch_done[b]) (void)hipEventDestroy(h->ev_epoch_done[b]);
     }
+    if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); }
+    if (h->ev_delta_ready) (void)hipEventDestroy(h->ev_delta_ready);
+    for (int b = 0; b < 2; ++b) if (h->ev_reduced[b]) (void)hipEventDestroy(h->ev_reduced[b]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->rng_stream) (void)hipStreamDestroy(h->rng_stream);
     if (h->h_draws) (void)hipHostFree(h->h_draws);

@@ -26,6 +26,11 @@ int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s)
     return 0;
 }
 
+int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, hipStream_t s) {
+    CYMF_NCCL(ncclAllReduce(d_in, d_out, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
+    return 0;
+}
+
 int comm_world(cymf_comm *c) { return c ? c->world : 1; }
 int comm_rank(cymf_comm *c) { return c ? c->rank : 0; }
 

@@ -31,10 +31,12 @@ def _problem():
 
 
 def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce, world=None, lr=0.05, wd=0.01, corrected=True,
-                       optimizer="sgd"):
+                       optimizer="sgd", delayed=True):
     """One process's part: rank_shards = list of (rank, shard) this process emulates.  The ranks' deltas
     are combined as the library does: H = snapshot + s_i * sum of deltas with the sequentialisation
-    factors of cymf_amd.dist.delta_scale (host mirror of build_delta_scales in csrc/bpr.hip)."""
+    factors of cymf_amd.dist.delta_scale (host mirror of build_delta_scales in csrc/bpr.hip).
+    delayed (the library's default, the overlapped exchange): the sum of step s is applied after step s+1 has
+    been computed -- H += s_i * sum(deltas of step s) - own delta of step s -- and once more at the end."""
     import oracle
     from cymf_amd import dist
     U, I = X.shape
@@ -45,7 +47,7 @@ def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce
     for rank, shard in rank_shards:
         W, H = W0.copy(), H0.copy()
         u_l, p_l, gpos = dist.shard_triplets(users, positives, shard)
-        state[rank] = dict(W=W, H=H, snap=H.copy(), m=oracle.Bpr(W, H, optimizer, lr, wd), u=u_l, p=p_l, g=gpos,
+        state[rank] = dict(W=W, H=H, snap=H.copy(), base=H.copy(), m=oracle.Bpr(W, H, optimizer, lr, wd), u=u_l, p=p_l, g=gpos,
                            step=dist.step_of(gpos, S, N), seen=np.zeros(N, dtype=np.int64))
     world = world or len(rank_shards)
     step_glob = dist.step_of(np.arange(N), S, N)      # the global windows are known to every rank
@@ -67,8 +69,20 @@ def _run_rank_schedule(rank_shards, X, users, positives, K, S, epochs, allreduce
             deltas = {rank: st["H"] - st["snap"] for rank, st in state.items()}
             total = allreduce(deltas) * scales[s][:, None]                    # sum over ALL ranks of the job, damped
             for rank, st in state.items():
-                st["H"][:] = st["snap"] + total
-                st["snap"][:] = st["H"]
+                if delayed:                                                   # base: the state all ranks agree on bit for bit
+                    if "pending" in st:
+                        st["base"] += st["pending"]
+                        st["H"][:] = st["base"] + deltas[rank]
+                    st["pending"] = total
+                    st["snap"][:] = st["H"]
+                else:
+                    st["H"][:] = st["snap"] + total
+                    st["snap"][:] = st["H"]
+    for st in state.values():                                                 # flush (cymf_bpr_sync / download)
+        if "pending" in st:
+            st["base"] += st["pending"]
+            st["H"][:] = st["base"]
+            del st["pending"]
     return state
 
 
@@ -150,7 +164,7 @@ def test_delta_sum_needs_the_sequentialisation_factor():
     for world, corrected in ((1, True), (6, False), (6, True)):
         shards = dist.user_shards(X.indptr, world)
         st = _run_rank_schedule(list(enumerate(shards)), X, users, positives, 8, 1, 7, lambda d: sum(d.values()),
-                                world=world, lr=lr, wd=wd, corrected=corrected)
+                                world=world, lr=lr, wd=wd, corrected=corrected, delayed=corrected)   # plain sum: applied at once
         out[(world, corrected)] = float(np.abs(st[0]["H"]).max())
     assert out[(6, False)] > 50 * out[(1, True)]          # plain sum: blows up
     assert out[(6, True)] < 3 * out[(1, True)] + 1e-3     # damped sum: bounded like the single rank
@@ -176,7 +190,7 @@ def test_adaptive_optimizers_shard_with_private_state(optimizer, lr):
     for world, corrected in ((1, True), (6, False), (6, True)):
         shards = dist.user_shards(X.indptr, world)
         st = _run_rank_schedule(list(enumerate(shards)), X, users, positives, 8, 1, 6, lambda d: sum(d.values()),
-                                world=world, lr=lr, wd=0.01, corrected=corrected, optimizer=optimizer)
+                                world=world, lr=lr, wd=0.01, corrected=corrected, optimizer=optimizer, delayed=corrected)
         out[(world, corrected)] = (float(np.abs(st[0]["H"]).max()), sum(s["loss"] for s in st.values()))
     assert out[(6, False)][0] > 3 * out[(1, True)][0]                 # plain sum: item factors run away
     assert out[(6, True)][0] < 2.5 * out[(1, True)][0]                # damped: same scale as the single rank

@@ -18,7 +18,10 @@ def _inputs(X, seed=5):
     return r[p].astype(np.int32), c[p].astype(np.int32), X.indptr.astype(np.int32), X.indices.astype(np.int32)
 
 
-def test_rccl_world1_allreduce_and_trainer_exchange():
+@pytest.mark.parametrize("sync_exchange", ["0", "1"])
+def test_rccl_world1_allreduce_and_trainer_exchange(sync_exchange, monkeypatch):
+    # "0": overlapped exchange (default; the all-reduce of step s runs under the kernel of step s+1), "1": exchange, then step
+    monkeypatch.setenv("CYMF_BPR_SYNC_EXCHANGE", sync_exchange)
     comm = dist.Comm(0, 1, 0, dist.Comm.unique_id())
     a = np.arange(1000, dtype=np.float32)
     assert np.array_equal(comm.allreduce(a), a) and np.array_equal(comm.allreduce(a, op="max"), a)
