@@ -112,7 +112,7 @@ __device__ __forceinline__ void opt_update(const OptParams<T> &o, T &p, T &s0, T
             const T bound = s0 * s0 * (o.omb2 * (T(1) - o.b1 * o.b1 / o.b2) / (o.omb1 * o.omb1));
             v = v < bound ? bound : v;
         }
-        if constexpr (HOG && sizeof(T) == 4) p -= o.lr * (s0 * o.inv_omb1) * __frcp_rn(fsqrt(v * o.inv_omb2) + o.eps);
+        if constexpr (HOG && sizeof(T) == 4) p -= o.lr * (s0 * o.inv_omb1) * __builtin_amdgcn_rcpf(fsqrt(v * o.inv_omb2) + o.eps);
         else p -= o.lr * (s0 / o.omb1) / (fsqrt(v / o.omb2) + o.eps);
     }
 }

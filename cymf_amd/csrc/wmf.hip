@@ -322,7 +322,7 @@ __device__ __forceinline__ void group_sync() {
 }
 
 __device__ __forceinline__ float rcp_nr(float d) {   // v_rcp_f32 + one Newton step
-    const float y = __frcp_rn(d);
+    const float y = __builtin_amdgcn_rcpf(d);
     return y * (2.0f - d * y);
 }
 
