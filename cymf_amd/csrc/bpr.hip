@@ -823,7 +823,6 @@ bool csr_has(const std::vector<int32_t> &indptr, const std::vector<int32_t> &ind
     return std::binary_search(b, e, item);
 }
 
-// ---- negatives of epoch `e` into d_draws[e & 1]; generated in stream order on rng_stream
 // overlapped exchange: wait for the all-reduce in flight (if any) and apply it (correct_delta_kernel); local_cur is
 // the delta of the step just computed (nullptr when flushing: then H ends equal to the common base on every rank).
 // With nothing in flight the reference point is simply refreshed (snapshot_if_idle).
@@ -843,6 +842,7 @@ int finish_exchange(cymf_bpr *h, bool snapshot_if_idle, const float *local_cur =
     return 0;
 }
 
+// ---- negatives of epoch `e` into d_draws[e & 1]; generated in stream order on rng_stream
 int request_epoch_draws(cymf_bpr *h, int64_t e) {
     while (h->epochs_generated <= e) {
         const int64_t g = h->epochs_generated;
