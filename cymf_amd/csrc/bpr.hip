@@ -17,6 +17,7 @@
 #include "store.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 namespace cymf {
@@ -115,13 +116,19 @@ __global__ __launch_bounds__(256) void bpr_level_kernel(BprDev<T> d, const int32
 // fence and the rows are loaded after an acquire fence (which also drops the CU's L1 lines).
 constexpr unsigned int TICKET_SPIN_LIMIT = 1u << 20;   // polls of >= 0.2 us each; a healthy schedule waits < 10 ms for a turn
 
-__device__ __forceinline__ bool ticket_wait(const unsigned int *ctr, unsigned int turn) {
+// all three counters are read in one round trip per poll (three sequential waits cost three round trips per triplet
+// even when every turn has already come)
+__device__ __forceinline__ bool ticket_wait3(const unsigned int *c0, unsigned int t0, const unsigned int *c1, unsigned int t1,
+                                             const unsigned int *c2, unsigned int t2) {
     unsigned int spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != turn) {
-        __builtin_amdgcn_s_sleep(2);
+    while (true) {
+        const unsigned int v0 = __hip_atomic_load(c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int v1 = __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int v2 = __hip_atomic_load(c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v0 == t0 && v1 == t1 && v2 == t2) return true;
+        __builtin_amdgcn_s_sleep(1);
         if (++spins > TICKET_SPIN_LIMIT) return false;
     }
-    return true;
 }
 
 template <typename T, int R, bool PACKED, int OPT>
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void bpr_ticket_kernel(BprDev<T> d, const int3
     while (l < n) {
         const int64_t l_next = grab();   // asked for early: its latency hides behind this triplet's waits and loads
         const int32_t u = tu[l], i = ti[l], j = tj[l];
-        const bool ok = ticket_wait(doneW + u, ku[l]) && ticket_wait(doneH + i, ki[l]) && ticket_wait(doneH + j, kj[l]);
+        const bool ok = ticket_wait3(doneW + u, ku[l], doneH + i, ki[l], doneH + j, kj[l]);
         if (!ok) {   // cannot happen with a consistent schedule; never hang the device on a bad one
             if (lane == 0) atomicExch(err, 1);
             break;
@@ -645,8 +652,10 @@ struct cymf_bpr {
     bool epoch_sampled = false;     // slot_neg holds epoch_cursor's negatives
 
     // exact mode scratch
-    uint32_t *h_draws = nullptr;   // pinned (hipHostMalloc): the exact mode reads the epoch's draws on the host
-    int64_t h_draws_cap = 0;
+    uint32_t *h_draws2[2] = {nullptr, nullptr};   // pinned (hipHostMalloc): the exact mode reads the epoch's draws on the host
+    int64_t h_draws_cap[2] = {0, 0};
+    int64_t exact_fetched = 0;
+    hipEvent_t ev_draws_host[2] = {nullptr, nullptr};
     std::vector<int32_t> h_last_neg;
     DevBuf<int32_t> d_tu, d_ti, d_tj;
     // exact mode, dataflow execution (bpr_ticket_kernel): turn numbers per triplet, finished-access counters per row
@@ -864,24 +873,39 @@ int fetch_loss(cymf_bpr *h, double *out) {
 }
 
 // =============================== EXACT epoch ===============================
+// draws of epoch g: generated on rng_stream and copied to pinned host memory of parity g & 1, all asynchronously
+int exact_fetch_draws(cymf_bpr *h, int64_t g) {
+    while (h->exact_fetched <= g) {
+        const int64_t q = h->exact_fetched;
+        const int b = (int)(q & 1);
+        CYMF_TRY(request_epoch_draws(h, q));
+        if (h->h_draws_cap[b] < h->N_global) {
+            if (h->h_draws2[b]) (void)hipHostFree(h->h_draws2[b]);
+            h->h_draws2[b] = nullptr;
+            CYMF_HIP(hipHostMalloc((void **)&h->h_draws2[b], (size_t)std::max<int64_t>(h->N_global, 1) * sizeof(uint32_t)));
+            h->h_draws_cap[b] = h->N_global;
+        }
+        CYMF_HIP(hipMemcpyAsync(h->h_draws2[b], h->d_draws[b].p, (size_t)h->N_global * sizeof(uint32_t), hipMemcpyDeviceToHost, h->rng_stream));
+        CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->rng_stream));     // d_draws[b] may be regenerated after this copy
+        CYMF_HIP(hipEventRecord(h->ev_draws_host[b], h->rng_stream));
+        h->exact_fetched++;
+    }
+    return 0;
+}
+
 template <typename T>
 int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
+    static const bool dbg_t = getenv("CYMF_DEBUG_TIMING") != nullptr;   // host-side phases of an exact epoch to stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_entry = now();
     const int64_t e = h->epoch_cursor;
     const int b = (int)(e & 1);
-    CYMF_TRY(request_epoch_draws(h, e));
-    if (h->h_draws_cap < h->N_global) {
-        if (h->h_draws) (void)hipHostFree(h->h_draws);
-        h->h_draws = nullptr;
-        CYMF_HIP(hipHostMalloc((void **)&h->h_draws, (size_t)h->N_global * sizeof(uint32_t)));
-        h->h_draws_cap = h->N_global;
-    }
-    CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_gen[b], 0));
-    CYMF_HIP(hipMemcpyAsync(h->h_draws, h->d_draws[b].p, (size_t)h->N_global * sizeof(uint32_t),
-                            hipMemcpyDeviceToHost, h->stream));
-    CYMF_HIP(hipStreamSynchronize(h->stream));
-    CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->stream));
+    CYMF_TRY(exact_fetch_draws(h, e));                  // (already on its way since the previous epoch, except the first time)
+    CYMF_HIP(hipEventSynchronize(h->ev_draws_host[b]));
+    const uint32_t *h_draws = h->h_draws2[b];
 
     const int64_t N = h->N;
+    const double t_draws = now();
     if (h->exact_tickets) {
         // turns (host): triplet l is access number ku of W[u], ki of H[i], kj of H[j] in sequential order
         std::vector<uint32_t> cntW((size_t)h->U, 0u), cntH((size_t)h->I, 0u);
@@ -892,7 +916,7 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
         ku.reserve((size_t)N); ki.reserve((size_t)N); kj.reserve((size_t)N);
         for (int64_t l = 0; l < N; ++l) {
             const int32_t u = h->h_users[l], i = h->h_pos_items[l];
-            const int32_t j = (int32_t)h->h_draws[h->h_gpos[l]];
+            const int32_t j = (int32_t)h_draws[h->h_gpos[l]];
             const bool positive = h->h_pos_bits.empty() ? csr_has(h->h_indptr, h->h_indices, u, j)
                                                         : (h->h_pos_bits[((size_t)u * h->I + j) >> 6] >> (((size_t)u * h->I + j) & 63)) & 1;
             if (positive) continue;                                    // bpr.pyx:166-167
@@ -901,6 +925,7 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
             ku.push_back(cntW[u]++); ki.push_back(cntH[i]++); kj.push_back(cntH[j]++);
         }
         const int64_t n_perf = (int64_t)tu.size(), n_skipped = N - n_perf;
+        const double t_turns = now();
         CYMF_TRY(h->d_tu.upload_into(tu.data(), tu.size(), (size_t)N, h->stream));
         CYMF_TRY(h->d_ti.upload_into(ti.data(), ti.size(), (size_t)N, h->stream));
         CYMF_TRY(h->d_tj.upload_into(tj.data(), tj.size(), (size_t)N, h->stream));
@@ -920,6 +945,7 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
             CYMF_HIP(hipEventCreate(&p0)); CYMF_HIP(hipEventCreate(&p1));
             CYMF_HIP(hipEventRecord(p0, h->stream));
         }
+        const double t_up = now();
         if (n_perf > 0)
             CYMF_TRY(launch_ticket<T>(h->K, h->opt, d, h->d_tu.p, h->d_ti.p, h->d_tj.p, h->d_ku.p, h->d_ki.p, h->d_kj.p, n_perf,
                                       h->d_done.p, h->d_done.p + h->U, h->d_next.p, h->d_loss.p, h->d_err.p, h->n_cu, h->stream));
@@ -929,10 +955,15 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
             h->prof_launches += 1;
             h->prof_units += n_perf;
         }
+        // the next epoch's draws are generated and copied to the host now, under this epoch's kernel: a one-workgroup
+        // generator on an otherwise idle GPU runs at idle clocks (measured 20-28 ms instead of 0.8 ms on some boxes)
+        CYMF_TRY(exact_fetch_draws(h, e + 1));
         int err = 0;
         CYMF_HIP(hipMemcpyAsync(&err, h->d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         double loss = 0;
         CYMF_TRY(fetch_loss(h, &loss));
+        if (dbg_t) fprintf(stderr, "[exact] draws %.2f ms, turns %.2f ms, uploads+memsets %.2f ms, launch+kernel+readback %.2f ms\n",
+                           t_draws - t_entry, t_turns - t_draws, t_up - t_turns, now() - t_up);
         if (err) return fail(CYMF_ERR_HIP, "exact mode: a wavefront waited past the spin limit for its turn (inconsistent schedule)");
         if (loss_out) *loss_out = N ? loss / (double)N : 0.0;   // bpr.pyx:171
         h->performed += n_perf;
@@ -947,7 +978,7 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
     int64_t n_skipped = 0;
     for (int64_t l = 0; l < N; ++l) {
         const int32_t u = h->h_users[l], i = h->h_pos_items[l];
-        const int32_t j = (int32_t)h->h_draws[h->h_gpos[l]];
+        const int32_t j = (int32_t)h_draws[h->h_gpos[l]];
         if (csr_has(h->h_indptr, h->h_indices, u, j)) { ++n_skipped; continue; }   // bpr.pyx:166-167
         h->h_last_neg[l] = j;
         int32_t lv = std::max(lastW[u], std::max(lastH[i], lastH[j])) + 1;
@@ -1317,6 +1348,7 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
         e = hipEventCreateWithFlags(&h->ev_gen[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_epoch_done[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_draws_host[b], hipEventDisableTiming);
     }
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
     int rc = h->d_loss.alloc(1);
@@ -1588,7 +1620,7 @@ extern "C" int cymf_bpr_destroy(cymf_bpr *h) {
     for (int b = 0; b < 2; ++b) if (h->ev_reduced[b]) (void)hipEventDestroy(h->ev_reduced[b]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->rng_stream) (void)hipStreamDestroy(h->rng_stream);
-    if (h->h_draws) (void)hipHostFree(h->h_draws);
+    for (int b = 0; b < 2; ++b) { if (h->h_draws2[b]) (void)hipHostFree(h->h_draws2[b]); if (h->ev_draws_host[b]) (void)hipEventDestroy(h->ev_draws_host[b]); }
     delete h;
     return 0;
 }
