@@ -1,5 +1,7 @@
 """Host-side pieces every trainer shares: input coercion, the reference's initialisation and
 shuffle (global legacy numpy state), progress bar, early-stopping bookkeeping."""
+import threading
+
 import numpy as np
 from scipy import sparse
 
@@ -20,6 +22,12 @@ def coerce_csr(X):
     else:
         raise ValueError()
     return X.astype(np.float64)
+
+
+# The reference draws initial factors and the shuffle from numpy's GLOBAL legacy state.  fit() holds this lock while it
+# does, so that several ranks running as threads of one process (tests with dist.Comm.local_group) each get the
+# sequence a process of their own would get.
+GLOBAL_RNG_LOCK = threading.RLock()
 
 
 def init_factors(model, U, I, K):

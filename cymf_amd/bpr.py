@@ -44,8 +44,9 @@ class BPR(object):
         if early_stopping and self.valid_evaluator is None:
             raise ValueError()                                   # cymf/bpr.pyx:94-95
         U, I = X.shape
-        _host.init_factors(self, U, I, self.num_components)
-        users, positives = _host.reference_shuffle(*X.nonzero())  # cymf/bpr.pyx:104
+        with _host.GLOBAL_RNG_LOCK:
+            _host.init_factors(self, U, I, self.num_components)
+            users, positives = _host.reference_shuffle(*X.nonzero())  # cymf/bpr.pyx:104
         users = users.astype(np.int32)
         positives = positives.astype(np.int32)
         indptr, indices = _host.membership_pattern(X)

@@ -5,11 +5,33 @@
 
 #include "common.h"
 
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
 static_assert(NCCL_UNIQUE_ID_BYTES == CYMF_UNIQUE_ID_BYTES, "unique id size");
+
+// A "local group" is N communicator handles inside ONE process on ONE device (cymf_comm_create_local_group): the
+// collectives are small kernels that meet in device memory.  It exists so that the sharded trainers can be run
+// with several ranks on a one-GPU test box -- RCCL refuses two ranks on one device -- one host thread per rank.
+struct LocalGroup {
+    int world = 0, device = 0, refs = 0;
+    size_t cap = 0;                      // floats per slot
+    float *slots = nullptr;              // [2 parities][world][cap], uncached
+    // host-side meeting point of the ranks' threads (no kernel ever waits on the device: a spinning kernel would
+    // deadlock against the device-wide synchronisation inside another rank's hipFree)
+    std::mutex mu;
+    std::condition_variable cv;
+    long long arrived = 0;               // total arrivals
+    bool broken = false;                 // a rank gave up waiting
+};
 
 struct cymf_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
+    LocalGroup *grp = nullptr;
+    long long gen = 0;                   // collectives issued by this rank (all ranks issue the same sequence)
 };
 
 #define CYMF_NCCL(expr)                                                                         \
@@ -19,14 +41,82 @@ struct cymf_comm {
             return ::cymf::fail(CYMF_ERR_RCCL, "%s failed: %s", #expr, ncclGetErrorString(r__)); \
     } while (0)
 
+
+namespace cymf {
+namespace {
+
+__global__ void local_publish_kernel(const float *__restrict__ in, float *__restrict__ slot, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) slot[i] = in[i];
+}
+// out = reduction over the ranks' slots in rank order (the same bits on every rank); op 0 sum, 1 max
+__global__ void local_reduce_kernel(const float *__restrict__ slots, size_t cap, int world, float *__restrict__ out, int64_t n, int op) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = slots[i];
+        for (int r = 1; r < world; ++r) { const float w = slots[(size_t)r * cap + i]; v = op == 1 ? (w > v ? w : v) : v + w; }
+        out[i] = v;
+    }
+}
+__global__ void local_copy_bytes_kernel(const unsigned char *__restrict__ in, unsigned char *__restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+
+inline int blocks_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+
+// every rank: publish my data into my slot of parity p (and wait for that on the host), meet the other ranks'
+// threads, then `consume` all slots (also waited for).  Two parities suffice: a rank reaches collective g+2 only
+// after every rank has arrived at g+1, i.e. has left collective g with its reads done.
+template <typename Publish, typename Consume>
+int local_collective(cymf_comm *c, size_t floats_needed, hipStream_t s, Publish publish, Consume consume) {
+    LocalGroup *g = c->grp;
+    if (floats_needed > g->cap) return fail(CYMF_ERR_UNSUPPORTED, "local group: %zu floats exceed the slot size %zu", floats_needed, g->cap);
+    const int p = (int)(c->gen & 1);
+    float *my_slot = g->slots + ((size_t)p * g->world + c->rank) * g->cap;
+    publish(my_slot);
+    CYMF_HIP(hipGetLastError());
+    CYMF_HIP(hipStreamSynchronize(s));
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->arrived++;
+        const long long target = (long long)g->world * (c->gen + 1);
+        g->cv.notify_all();
+        if (!g->cv.wait_for(lk, std::chrono::seconds(20), [&] { return g->arrived >= target || g->broken; }) || g->broken) {
+            g->broken = true;
+            g->cv.notify_all();
+            return fail(CYMF_ERR_RCCL, "local group: rank %d waited 20 s for the others at collective %lld", c->rank, c->gen);
+        }
+    }
+    consume(g->slots + (size_t)p * g->world * g->cap);
+    CYMF_HIP(hipGetLastError());
+    CYMF_HIP(hipStreamSynchronize(s));   // a rank leaves the collective with its reads of the slots done
+    c->gen++;
+    return 0;
+}
+
+int local_allreduce(cymf_comm *c, const float *d_in, float *d_out, int64_t n, int op, hipStream_t s) {
+    return local_collective(c, (size_t)n, s,
+        [&](float *slot) { hipLaunchKernelGGL(local_publish_kernel, dim3(blocks_for(n)), dim3(256), 0, s, d_in, slot, n); },
+        [&](const float *slots) { hipLaunchKernelGGL(local_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, s, slots, c->grp->cap, c->world, d_out, n, op); });
+}
+
+}  // namespace
+}  // namespace cymf
+
 namespace cymf {
 
 int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s) {
+    if (c->grp) return local_allreduce(c, d_buf, d_buf, n, 0, s);
     CYMF_NCCL(ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
     return 0;
 }
 
 int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, hipStream_t s) {
+    if (c->grp) return local_allreduce(c, d_in, d_out, n, 0, s);
     CYMF_NCCL(ncclAllReduce(d_in, d_out, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
     return 0;
 }
@@ -38,6 +128,26 @@ int comm_rank(cymf_comm *c) { return c ? c->rank : 0; }
 // table at d_buf and every rank ends with all of them.  One grouped set of broadcasts (RCCL fuses the group).
 int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_t row_bytes, hipStream_t s) {
     if (c->world == 1) return 0;
+    if (c->grp) {   // my rows into my slot (as bytes), then everybody copies every other rank's rows out of the slots
+        const int64_t my_bytes = (row_bounds[c->rank + 1] - row_bounds[c->rank]) * row_bytes;
+        int64_t max_bytes = 0;
+        for (int r = 0; r < c->world; ++r) max_bytes = std::max<int64_t>(max_bytes, (row_bounds[r + 1] - row_bounds[r]) * row_bytes);
+        unsigned char *base = static_cast<unsigned char *>(d_buf);
+        return local_collective(c, (size_t)(max_bytes + 3) / 4, s,
+            [&](float *slot) {
+                if (my_bytes > 0)
+                    hipLaunchKernelGGL(local_copy_bytes_kernel, dim3(blocks_for(my_bytes)), dim3(256), 0, s, base + row_bounds[c->rank] * row_bytes,
+                                       reinterpret_cast<unsigned char *>(slot), my_bytes);
+            },
+            [&](const float *slots) {
+                for (int r = 0; r < c->world; ++r) {
+                    const int64_t nb = (row_bounds[r + 1] - row_bounds[r]) * row_bytes;
+                    if (r == c->rank || nb <= 0) continue;
+                    hipLaunchKernelGGL(local_copy_bytes_kernel, dim3(blocks_for(nb)), dim3(256), 0, s,
+                                       reinterpret_cast<const unsigned char *>(slots + (size_t)r * c->grp->cap), base + row_bounds[r] * row_bytes, nb);
+                }
+            });
+    }
     CYMF_NCCL(ncclGroupStart());
     for (int r = 0; r < c->world; ++r) {
         const int64_t n = (row_bounds[r + 1] - row_bounds[r]) * row_bytes;
@@ -82,10 +192,34 @@ extern "C" int cymf_comm_create(cymf_comm **out, const char id[CYMF_UNIQUE_ID_BY
     return 0;
 }
 
+extern "C" int cymf_comm_create_local_group(cymf_comm **out, int world, int device, int64_t max_floats) {
+    if (!out || world < 1 || world > 16 || max_floats < 1) return fail(CYMF_ERR_INVALID, "cymf_comm_create_local_group: bad arguments");
+    CYMF_TRY(use_device(device));
+    LocalGroup *g = new LocalGroup();
+    g->world = world; g->device = device; g->refs = world; g->cap = ((size_t)max_floats + 63) & ~(size_t)63;
+    hipError_t e = hipExtMallocWithFlags((void **)&g->slots, 2 * (size_t)world * g->cap * sizeof(float), hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        if (g->slots) (void)hipFree(g->slots);
+        delete g;
+        return fail(CYMF_ERR_NOMEM, "cymf_comm_create_local_group: %s", hipGetErrorString(e));
+    }
+    for (int r = 0; r < world; ++r) {
+        cymf_comm *c = new cymf_comm();
+        c->rank = r; c->world = world; c->device = device; c->grp = g;
+        out[r] = c;
+    }
+    return 0;
+}
+
 extern "C" int cymf_comm_destroy(cymf_comm *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->grp && --c->grp->refs == 0) {   // (handles of a local group are destroyed from one thread, after the ranks have joined)
+        (void)hipDeviceSynchronize();
+        (void)hipFree(c->grp->slots);
+        delete c->grp;
+    }
     delete c;
     return 0;
 }
@@ -95,6 +229,17 @@ extern "C" int cymf_comm_allreduce_f32(cymf_comm *c, float *host_inout, int64_t 
     CYMF_TRY(use_device(c->device));
     DevBuf<float> d;
     CYMF_TRY(d.upload(host_inout, (size_t)n));
+    if (c->grp) {   // (no device-wide synchronisation here: another rank's thread may be blocked inside a collective)
+        hipStream_t s = nullptr;
+        CYMF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        DevBuf<float> dl;
+        int rc = dl.upload(host_inout, (size_t)n, s);
+        if (!rc) rc = local_allreduce(c, dl.p, dl.p, n, op == 1 ? 1 : 0, s);
+        if (!rc && hipMemcpyAsync(host_inout, dl.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(CYMF_ERR_HIP, "copy failed");
+        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(CYMF_ERR_HIP, "sync failed");
+        (void)hipStreamDestroy(s);
+        return rc;
+    }
     CYMF_HIP(hipDeviceSynchronize());
     CYMF_NCCL(ncclAllReduce(d.p, d.p, (size_t)n, ncclFloat32, op == 1 ? ncclMax : ncclSum, c->comm, nullptr));
     CYMF_HIP(hipMemcpy(host_inout, d.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));

@@ -82,6 +82,20 @@ class Comm:
         buf = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
         _lib.check(self.L.cymf_comm_create(C.byref(self.h), buf, rank, world, device))
 
+    @classmethod
+    def local_group(cls, world, max_floats, device=0):
+        """world communicators inside this process on one device (cymf_comm_create_local_group): run one rank per
+        host thread.  For tests on a one-GPU box; RCCL needs one device per rank."""
+        L = _lib.lib()
+        arr = (C.c_void_p * world)()
+        _lib.check(L.cymf_comm_create_local_group(arr, int(world), int(device), int(max_floats)))
+        out = []
+        for r in range(world):
+            c = cls.__new__(cls)
+            c.L, c.rank, c.world, c.device, c.h = L, r, world, device, C.c_void_p(arr[r])
+            out.append(c)
+        return out
+
     @staticmethod
     def unique_id():
         buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)

@@ -21,7 +21,7 @@ class GloVe(object):
         self.x_max = float(x_max)
         self.W = None
 
-    def fit(self, X, num_epochs, num_threads, verbose=False, *, mode=None, dtype=None, device=0, comm=None, steps_per_epoch=1):
+    def fit(self, X, num_epochs, num_threads, verbose=False, *, mode=None, dtype=None, device=0, comm=None, steps_per_epoch=1, seed=None):
         """cymf/glove.pyx:75-112.  No seeding here either: initial factors come from the caller's
         global numpy state (glove.pyx:91-94).
         comm (a dist.Comm, one process per GPU, throughput mode): every rank passes the same X and the same numpy
@@ -32,13 +32,16 @@ class GloVe(object):
         if not isinstance(X, (sparse.lil_matrix, sparse.csr_matrix, sparse.csc_matrix)):
             raise TypeError("X must be a type of scipy.sparse.*_matrix.")
         K = self.num_components
-        self.W = np.random.uniform(low=-0.5, high=0.5, size=(X.shape[0], K)) / K
-        self.bias = np.random.uniform(low=-0.5, high=0.5, size=(X.shape[0],)) / K
-        _W = np.random.uniform(low=-0.5, high=0.5, size=(X.shape[1], K)) / K
-        _bias = np.random.uniform(low=-0.5, high=0.5, size=(X.shape[0],)) / K
-        central_words, context_words = X.nonzero()
-        counts = X.data
-        central_words, context_words, counts = _host.reference_shuffle(central_words, context_words, counts)
+        with _host.GLOBAL_RNG_LOCK:
+            if seed is not None:                                    # (extension: the reference leaves the seeding to the caller)
+                np.random.seed(seed)
+            self.W = np.random.uniform(low=-0.5, high=0.5, size=(X.shape[0], K)) / K
+            self.bias = np.random.uniform(low=-0.5, high=0.5, size=(X.shape[0],)) / K
+            _W = np.random.uniform(low=-0.5, high=0.5, size=(X.shape[1], K)) / K
+            _bias = np.random.uniform(low=-0.5, high=0.5, size=(X.shape[0],)) / K
+            central_words, context_words = X.nonzero()
+            counts = X.data
+            central_words, context_words, counts = _host.reference_shuffle(central_words, context_words, counts)
         mode = _host.pick_mode(mode, num_threads)
         dtype = _host.pick_dtype(dtype, mode)
         bounds = None

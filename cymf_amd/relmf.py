@@ -34,7 +34,8 @@ class RelMF(object):
         self.early_stopping = early_stopping
         propensities = np.maximum(X.mean(axis=0) / X.mean(axis=0).max(), 1e-5) ** 0.5   # cymf/relmf.pyx:88
         U, I = X.shape
-        _host.init_factors(self, U, I, self.num_components)
+        with _host.GLOBAL_RNG_LOCK:
+            _host.init_factors(self, U, I, self.num_components)
         mode = _host.pick_mode(mode, num_threads)
         dtype = _host.pick_dtype(dtype, mode)
         trainer = RelMfTrainer(U, I, self.num_components, self.optimizer, self.learning_rate, self.weight_decay,

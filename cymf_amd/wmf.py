@@ -33,7 +33,8 @@ class WMF(object):
         if early_stopping and self.valid_evaluator is None:
             raise ValueError()
         U, I = X.shape
-        _host.init_factors(self, U, I, self.num_components)
+        with _host.GLOBAL_RNG_LOCK:
+            _host.init_factors(self, U, I, self.num_components)
         Xt = X.T.tocsr()                                          # wmf.pyx:112
         trainer = WmfTrainer(U, I, self.num_components, self.weight, self.weight_decay, dtype=dtype,
                              device=device if comm is None else comm.device, comm=comm)

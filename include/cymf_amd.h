@@ -117,6 +117,10 @@ int cymf_comm_unique_id(char id[CYMF_UNIQUE_ID_BYTES]);                     /* r
 int cymf_comm_create(cymf_comm **out, const char id[CYMF_UNIQUE_ID_BYTES], int rank, int world,
                      int device);
 int cymf_comm_destroy(cymf_comm *c);
+/* world handles inside ONE process on ONE device whose collectives meet in device memory (slots of max_floats floats per
+ * rank): lets the sharded trainers run as several ranks, one host thread each, on a one-GPU box -- RCCL refuses two ranks
+ * on one device.  A test and debugging vehicle, not a transport. */
+int cymf_comm_create_local_group(cymf_comm **out, int world, int device, int64_t max_floats);
 /* host buffer all-reduce (op 0 = sum, 1 = max): rendezvous/timing helper and test hook */
 int cymf_comm_allreduce_f32(cymf_comm *c, float *host_inout, int64_t n, int op);
 /* call before cymf_bpr_set_data (the per-step item counts are all-reduced there).  Throughput mode, any
