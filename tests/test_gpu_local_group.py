@@ -86,6 +86,29 @@ def test_bpr_three_ranks_on_one_gpu(optimizer, lr, sync_exchange, monkeypatch):
         c.close()
 
 
+def test_bpr_six_ranks_strong_contraction_stays_bounded():
+    """The regime in which a plain sum of the replicas' deltas diverges (tests/test_dist_gloo.py: many updates of a popular
+    item per rank and step, lr * wd = 0.01): six ranks, one step per epoch, 200 items -- the damped sums keep the
+    factors at the single-GPU scale."""
+    X = synthetic.implicit_matrix(1200, 200, 30000, 78)
+    K, world = 8, 6
+    comms = dist.Comm.local_group(world, 200 * K + 4 * 200 + 64)
+    shards = dist.user_shards(X.indptr, world)
+
+    def fn(r):
+        m = BPR(K, 0.05, "sgd", 0.2)
+        m.fit(X, num_epochs=7, num_threads=0, verbose=False, comm=comms[r], shard=shards[r], steps_per_epoch=1)
+        return m.H
+
+    res = _run_ranks(world, fn)
+    one = BPR(K, 0.05, "sgd", 0.2)
+    one.fit(X, num_epochs=7, num_threads=0, verbose=False, steps_per_epoch=1)
+    assert all(np.array_equal(H, res[0]) for H in res)
+    assert np.isfinite(res[0]).all() and np.abs(res[0]).max() < 3 * np.abs(one.H).max() + 1e-3
+    for c in comms:
+        c.close()
+
+
 def test_wmf_three_ranks_on_one_gpu():
     X = synthetic.implicit_matrix(900, 400, 30000, 92)
     world = 3
