@@ -1224,13 +1224,15 @@ int build_delta_scales(cymf_bpr *h, const std::vector<int32_t> &slot_item) {
         CYMF_HIP(hipMemcpyAsync(slots.data(), d2.p, slots.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         CYMF_HIP(hipStreamSynchronize(h->stream));
     }
-    // per-touch contraction of a replica towards its local equilibrium, by optimizer (all validated on the CPU
-    // emulation, tests/test_dist_gloo.py): SGD 2 lr wd (the isotropic part; the data term acts along one w per
-    // touch); AdaGrad never steps further than SGD (acc >= 1) but its early steps are data-dominated: lr/5;
-    // Adam moves every element by about lr per touch whatever the gradient: 5 lr.
-    double rho = 2.0 * h->lr * h->wd;
-    if (h->opt == CYMF_OPT_ADAGRAD) rho = std::max(rho, 0.2 * h->lr);
+    // per-touch contraction of a replica towards its local equilibrium, by optimizer.  SGD / AdaGrad: the weight decay
+    // contracts by lr*wd per touch and the data term (curvature sigma' w w^T along the user rows an item meets) by a
+    // multiple of lr that grows with the factor norms; measured with eight ranks on one GPU (tools/multirank_check.py,
+    // C3-shaped, lr 0.05, wd 0.01): rho = 0.001 (weight decay alone) lets the loss turn upwards after four epochs,
+    // 0.005 .. 0.1 track the single-rank run, 0.02 fits best -> 2 lr wd + 0.2 lr.  Adam moves every element by about lr per
+    // touch whatever the gradient: 5 lr (CPU emulation, tests/test_dist_gloo.py).
+    double rho = 2.0 * h->lr * h->wd + 0.2 * h->lr;
     if (h->opt == CYMF_OPT_ADAM) rho = 5.0 * h->lr;
+    if (const char *er = getenv("CYMF_BPR_DELTA_RHO")) rho = atof(er);   // experiments (tools/multirank_check.py)
     const double base = 1.0 - std::min(0.5, rho);
     for (int32_t s = 0; s < S; ++s)
         for (int32_t i = 0; i < h->I; ++i) {

@@ -55,10 +55,8 @@ def word_bounds(central, n_words, world):
 
 def delta_rho(optimizer, lr, wd):
     """Per-touch contraction assumed for a replica of an item row (host mirror of build_delta_scales, csrc/bpr.hip)."""
-    rho = 2.0 * lr * wd
-    if optimizer == "adagrad":
-        rho = max(rho, 0.2 * lr)
-    elif optimizer == "adam":
+    rho = 2.0 * lr * wd + 0.2 * lr
+    if optimizer == "adam":
         rho = 5.0 * lr
     return min(0.5, rho)
 

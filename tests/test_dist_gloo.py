@@ -168,9 +168,9 @@ def test_delta_sum_needs_the_sequentialisation_factor():
         out[(world, corrected)] = float(np.abs(st[0]["H"]).max())
     assert out[(6, False)] > 50 * out[(1, True)]          # plain sum: blows up
     assert out[(6, True)] < 3 * out[(1, True)] + 1e-3     # damped sum: bounded like the single rank
-    # and in the weakly contracting regime the factor is ~1 (plain sum): nothing is slowed down
+    # rarely touched rows keep (nearly) the plain sum: nothing is slowed down there
     s = dist.delta_scale(np.array([0.0, 5.0, 50.0]), 8, 0.05, 0.01)
-    assert s[0] == 1.0 and s[1] > 0.99 and 0.95 < s[2] < 1.0
+    assert s[0] == 1.0 and s[1] > 0.97 and 0.75 < s[2] < 0.85
     assert dist.delta_scale(np.array([1e6]), 8, 0.05, 0.01)[0] == pytest.approx(1 / 8, rel=1e-6)
     assert (dist.delta_scale(np.array([0.0, 10.0, 1e6]), 1, 0.05, 0.01) == 1.0).all()
 
@@ -195,5 +195,5 @@ def test_adaptive_optimizers_shard_with_private_state(optimizer, lr):
     assert out[(6, False)][0] > 3 * out[(1, True)][0]                 # plain sum: item factors run away
     assert out[(6, True)][0] < 2.5 * out[(1, True)][0]                # damped: same scale as the single rank
     assert out[(6, True)][1] < 0.7 * out[(6, False)][1]               # and a far lower last-epoch loss
-    assert dist.delta_rho("sgd", 0.05, 0.01) == pytest.approx(0.001) and dist.delta_rho("adam", 0.001, 0.01) == pytest.approx(0.005)
-    assert dist.delta_rho("adagrad", 0.05, 0.01) == pytest.approx(0.01) and dist.delta_rho("adam", 1.0, 0.01) == 0.5
+    assert dist.delta_rho("sgd", 0.05, 0.01) == pytest.approx(0.011) and dist.delta_rho("adam", 0.001, 0.01) == pytest.approx(0.005)
+    assert dist.delta_rho("adagrad", 0.05, 0.01) == pytest.approx(0.011) and dist.delta_rho("adam", 1.0, 0.01) == 0.5
