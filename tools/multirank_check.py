@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: the sharded BPR job with several ranks on ONE GPU (dist.Comm.local_group, one thread per rank)
 against the single-rank run on a C3-shaped problem scaled down (Zipf items, lognormal users).
-  python tools/multirank_check.py [world=8] [epochs=6]"""
+  [OPT=sgd LR=0.05 RHOS=default,0.005,...] python tools/multirank_check.py [world=8] [epochs=6]"""
 import os
 import sys
 import threading
@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from cymf_amd import dist, synthetic  # noqa: E402
 from cymf_amd.bpr import BprTrainer  # noqa: E402
 
+OPT, LR = os.environ.get("OPT", "sgd"), float(os.environ.get("LR", "0.05"))
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 U, I, nnz, K, S = 200_000, 20_000, 10_000_000, 64, 3 * 8 // max(world, 1) or 1
@@ -37,7 +38,7 @@ def run(world, sync):
             users, pos, gpos = rows[perm[mine]], cols[perm[mine]], mine.astype(np.int64)
         else:
             users, pos, gpos = rows[perm], cols[perm], None
-        t = BprTrainer(U, I, K, "sgd", 0.05, 0.01, mode="throughput", steps_per_epoch=spe, comm=comms[r])
+        t = BprTrainer(U, I, K, OPT, LR, 0.01, mode="throughput", steps_per_epoch=spe, comm=comms[r])
         t.set_data(users, pos, indptr.astype(np.int32), cols, gpos, nnz)
         t.upload(W0, H0)
         losses = [t.epochs(1)[0] * len(users) for _ in range(epochs)]
