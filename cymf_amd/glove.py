@@ -21,12 +21,13 @@ class GloVe(object):
         self.x_max = float(x_max)
         self.W = None
 
-    def fit(self, X, num_epochs, num_threads, verbose=False, *, mode=None, dtype=None, device=0, comm=None, steps_per_epoch=1, seed=None):
+    def fit(self, X, num_epochs, num_threads, verbose=False, *, mode=None, dtype=None, device=0, comm=None, steps_per_epoch=None, seed=None):
         """cymf/glove.pyx:75-112.  No seeding here either: initial factors come from the caller's
         global numpy state (glove.pyx:91-94).
         comm (a dist.Comm, one process per GPU, throughput mode): every rank passes the same X and the same numpy
         state; the pairs are sharded by central word, the context table is replicated and synchronised after each
-        of the steps_per_epoch steps; every rank ends with the same full tables."""
+        of the steps_per_epoch steps (default: 1 on one GPU, 4 per rank with a communicator -- few large steps learn
+        visibly slower across ranks); every rank ends with the same full tables."""
         if X is None:
             raise ValueError()
         if not isinstance(X, (sparse.lil_matrix, sparse.csr_matrix, sparse.csc_matrix)):
@@ -44,6 +45,8 @@ class GloVe(object):
             central_words, context_words, counts = _host.reference_shuffle(central_words, context_words, counts)
         mode = _host.pick_mode(mode, num_threads)
         dtype = _host.pick_dtype(dtype, mode)
+        if steps_per_epoch is None:
+            steps_per_epoch = 1 if comm is None else 4 * comm.world
         bounds = None
         n_all = len(counts)
         if comm is not None:

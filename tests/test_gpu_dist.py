@@ -106,7 +106,7 @@ def test_glove_with_world1_communicator_and_steps():
     comm = dist.Comm(0, 1, 0, dist.Comm.unique_id())
     X = synthetic.cooccurrence_matrix(800, 60000, 64)
     fits = {}
-    for name, kw in (("plain", {}), ("comm", dict(comm=comm)), ("comm3", dict(comm=comm, steps_per_epoch=3)), ("steps3", dict(steps_per_epoch=3))):
+    for name, kw in (("plain", {}), ("comm", dict(comm=comm, steps_per_epoch=1)), ("comm3", dict(comm=comm, steps_per_epoch=3)), ("steps3", dict(steps_per_epoch=3))):
         np.random.seed(5)
         m = GloVe(32, 0.05)
         m.fit(X, 3, 0, **kw)
