@@ -58,6 +58,7 @@ def lib():
         "cymf_comm_create_local_group": ([vp, ci, ci, i64], ci),
         "cymf_comm_allreduce_f32": ([vp, vp, i64, ci], ci),
         "cymf_bpr_attach_comm": ([vp, vp], ci),
+        "cymf_bpr_set_user_bounds": ([vp, vp], ci),
         "cymf_relmf_create": ([pp, i32, i32, i32, ci, f64, f64, f64, u32, ci, ci, ci], ci),
         "cymf_relmf_set_data": ([vp, vp, vp], ci),
         "cymf_relmf_upload": ([vp, vp, vp], ci),

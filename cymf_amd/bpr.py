@@ -61,6 +61,11 @@ class BPR(object):
         trainer = BprTrainer(U, I, self.num_components, self.optimizer, self.learning_rate, self.weight_decay,
                              dtype=dtype, mode=mode, device=device, steps_per_epoch=steps_per_epoch, comm=comm)
         try:
+            if comm is not None and shard is not None:
+                from .dist import user_shards
+                all_shards = user_shards(X.indptr, comm.world)            # the same cut on every rank
+                if tuple(all_shards[comm.rank]) == tuple(shard):
+                    trainer.set_user_bounds([lo for lo, _ in all_shards] + [all_shards[-1][1]])
             trainer.set_data(users, positives, indptr, indices, global_pos, n_global)
             trainer.upload(self.W, self.H)
             stopper = _host.EarlyStopping(self)
@@ -100,6 +105,11 @@ class BprTrainer:
             _lib.check(self.L.cymf_bpr_set_steps_per_epoch(self.h, int(steps_per_epoch)))
         if comm is not None:
             _lib.check(self.L.cymf_bpr_attach_comm(self.h, comm.h))
+
+    def set_user_bounds(self, bounds):
+        """User ranges of all ranks (world + 1 boundaries): download() then returns every rank's rows of W on every rank."""
+        b = np.ascontiguousarray(bounds, dtype=np.int64)
+        _lib.check(self.L.cymf_bpr_set_user_bounds(self.h, _lib.ptr(b)))
 
     def set_data(self, users, positives, indptr, indices, global_pos=None, n_global=None):
         users, positives = _lib.i32c(users), _lib.i32c(positives)

@@ -702,6 +702,7 @@ struct cymf_bpr {
     hipEvent_t ev_delta_ready = nullptr, ev_reduced[2] = {nullptr, nullptr};
     DevBuf<float> d_local[2], d_glob[2], d_base;
     bool exch_pending = false;
+    std::vector<int64_t> user_bounds;   // [world + 1] user ranges of the ranks: download() gathers the W rows (optional)
     int exch_parity = 0;
     int64_t exch_count = 0;
     const float *exch_scale = nullptr;
@@ -718,6 +719,8 @@ struct cymf_bpr {
 namespace cymf {
 int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s);   // comm.hip
 int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, hipStream_t s);
+int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_t row_bytes, hipStream_t s);
+int comm_rank(cymf_comm *c);
 int comm_world(cymf_comm *c);
 }
 
@@ -1496,6 +1499,8 @@ extern "C" int cymf_bpr_download(cymf_bpr *h, double *W, double *H) {
     if (!h->have_params) return fail(CYMF_ERR_INVALID, "cymf_bpr_download before cymf_bpr_upload");
     CYMF_TRY(use_device(h->device));
     if (h->comm && h->overlap_exchange) CYMF_TRY(finish_exchange(h, false));   // the last step's exchange is still in flight
+    if (h->comm && !h->user_bounds.empty() && h->dtype == CYMF_F32)               // every rank returns all user rows
+        CYMF_TRY(comm_allgatherv(h->comm, h->f32.W.p, h->user_bounds.data(), (int64_t)h->K * (int64_t)sizeof(float), h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
     const size_t nW = (size_t)h->U * h->K, nH = (size_t)h->I * h->K;
     if (h->dtype == CYMF_F32) { CYMF_TRY(download_f64(h->f32.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f32.H, H, nH, h->stream)); }
@@ -1602,6 +1607,16 @@ extern "C" int cymf_bpr_attach_comm(cymf_bpr *h, cymf_comm *c) {
         for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&h->ev_reduced[b], hipEventDisableTiming);
         if (e != hipSuccess) return fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
     }
+    return 0;
+}
+
+extern "C" int cymf_bpr_set_user_bounds(cymf_bpr *h, const int64_t *bounds) {
+    if (!h || !bounds || !h->comm) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_user_bounds: needs a handle with a communicator and the bounds");
+    const int world = comm_world(h->comm);
+    if (bounds[0] != 0 || bounds[world] != h->U) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_user_bounds: bounds must run from 0 to U");
+    for (int r = 0; r < world; ++r)
+        if (bounds[r] > bounds[r + 1]) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_user_bounds: bounds not monotone");
+    h->user_bounds.assign(bounds, bounds + world + 1);
     return 0;
 }
 

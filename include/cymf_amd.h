@@ -126,6 +126,9 @@ int cymf_comm_allreduce_f32(cymf_comm *c, float *host_inout, int64_t n, int op);
 /* call before cymf_bpr_set_data (the per-step item counts are all-reduced there).  Throughput mode, any
  * optimizer: only H is exchanged, optimizer state of the item rows stays private to the rank. */
 int cymf_bpr_attach_comm(cymf_bpr *h, cymf_comm *c);
+/* optional: the user ranges [bounds[r], bounds[r+1]) of all ranks; cymf_bpr_download then gathers the rows of W, so that
+ * every rank returns the whole trained model (without it a rank returns its own rows, the others at their initial values) */
+int cymf_bpr_set_user_bounds(cymf_bpr *h, const int64_t *bounds);
 
 /* ---------------------------------------------------------------- RelMF
  * replaces RelMF._fit_relmf, cymf/relmf.pyx:106-171 (loop :142-148) with
