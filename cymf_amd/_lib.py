@@ -65,6 +65,8 @@ def lib():
         "cymf_relmf_download": ([vp, vp, vp], ci),
         "cymf_relmf_epochs": ([vp, i32, vp], ci),
         "cymf_relmf_destroy": ([vp], ci),
+        "cymf_relmf_set_steps_per_epoch": ([vp, i32], ci),
+        "cymf_relmf_attach_comm": ([vp, vp, vp], ci),
         "cymf_glove_create": ([pp, i32, i32, i32, f64, f64, f64, ci, ci, ci], ci),
         "cymf_glove_set_data": ([vp, vp, vp, vp, i64], ci),
         "cymf_glove_upload": ([vp, vp, vp, vp, vp], ci),

@@ -499,6 +499,8 @@ struct RelStepDev {
     float wd, clip;
     OptParams<float> opt;
     int coherent;   // read the item rows with agent-scope atomic loads (CYMF_RELMF_COHERENT_LOADS, default 1)
+    int32_t u_lo, u_hi;         // users of this launch (multi-GPU: the rank's range; else 0 .. U)
+    int64_t turn_lo, turn_hi;   // turns of this launch (multi-GPU sub-steps; else 0 .. open end)
 };
 
 template <int R, bool PACKED, int OPT, int PF>
@@ -513,8 +515,8 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
     const int lane = lane_id();
     const int K = d.K;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t u_begin = wave * users_per_wave;
-    const int64_t u_end = u_begin + users_per_wave < U ? u_begin + users_per_wave : U;
+    const int64_t u_begin = d.u_lo + wave * users_per_wave;
+    const int64_t u_end = u_begin + users_per_wave < d.u_hi ? u_begin + users_per_wave : d.u_hi;
     float *const Ws[2] = {d.W0, d.W1};
     float *const Hs[2] = {d.H0, d.H1};
     float loss_sum = 0.0f;
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
     // a few long blocks, far from the random interleaving of the sequential order (measured: norm of H x2.2 with
     // nine users per wavefront back to back, 0.97 with every user on its own wavefront).
     constexpr int64_t TURN = 256;
-    for (int64_t turn0 = 0;; turn0 += TURN) {
+    for (int64_t turn0 = d.turn_lo * TURN; turn0 < d.turn_hi * TURN; turn0 += TURN) {
     bool any = false;
     for (int64_t u = u_begin; u < u_end; ++u) {
         const int64_t s_begin = off[u] + turn0;
@@ -607,9 +609,33 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
 #pragma unroll
         for (int q = 0; q < NS; ++q) sw[q].store(Ws[q] + u * K, K, lane);
     }
-    if (!any) break;
+    if (!any && d.turn_hi >= ((int64_t)1 << 40)) break;   // open-ended launch: stop when every user of the wave is through
     }
     if (lane == 0) atomicAdd(loss_acc, (double)loss_sum);
+}
+
+// Multi-GPU RelMF: users sharded (every rank generates the whole cell stream and buckets it, then works through its own
+// users), item table replicated.  After each sub-step (a range of turns) the deltas of H -- and of AdaGrad's accumulators,
+// which are plain sums -- are all-reduced; H gets the sequentialisation factor (uniform here: every item is touched about
+// U / steps times per sub-step), Adam's moments stay private to the rank.
+__global__ void relmf_delta_kernel(const float *__restrict__ H, const float *__restrict__ A, const float *__restrict__ sH,
+                                   const float *__restrict__ sA, float *__restrict__ D, int64_t n, int with_acc) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        D[i] = H[i] - sH[i];
+        if (with_acc) D[n + i] = A[i] - sA[i];
+    }
+}
+__global__ void relmf_apply_kernel(float *__restrict__ H, float *__restrict__ A, float *__restrict__ sH, float *__restrict__ sA,
+                                   const float *__restrict__ D, float scale, int64_t n, int with_acc) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float v = sH[i] + scale * D[i];
+        H[i] = v; sH[i] = v;
+        if (with_acc) { const float a = sA[i] + D[n + i]; A[i] = a; sA[i] = a; }
+    }
 }
 
 template <int R, bool PACKED>
@@ -764,6 +790,11 @@ struct cymf_relmf {
     DevBuf<int64_t> d_uoff[2];
     DevBuf<int32_t> d_items[2];
     int64_t epochs_prepared = 0, epoch_cursor = 0;
+    // multi-GPU: user ranges of the ranks, sub-steps per epoch, exchange buffers
+    cymf_comm *comm = nullptr;
+    std::vector<int64_t> user_bounds;
+    int32_t steps_per_epoch = 1;
+    DevBuf<float> d_snapH, d_snapA, d_xdelta;
     DevBuf<double> d_loss;
     DevBuf<int> d_err;
     std::vector<uint32_t> h_cells;
@@ -833,6 +864,9 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
             sd.X = st.X.p; sd.prop = st.prop.p; sd.K = h->K; sd.I = h->I; sd.wd = (float)h->wd; sd.clip = (float)h->clip;
             sd.opt = make_opt_params<float>(h->lr);
             sd.coherent = !(getenv("CYMF_RELMF_COHERENT_LOADS") && getenv("CYMF_RELMF_COHERENT_LOADS")[0] == '0');
+            sd.u_lo = 0; sd.u_hi = h->U; sd.turn_lo = 0; sd.turn_hi = (int64_t)1 << 40;
+            if (h->comm) { sd.u_lo = (int32_t)h->user_bounds[comm_rank(h->comm)]; sd.u_hi = (int32_t)h->user_bounds[comm_rank(h->comm) + 1]; }
+            const int32_t my_users = sd.u_hi - sd.u_lo;
             // whole users per wavefront; every user has about I draws, so equal user counts are equal work.
             // Staleness bound, as for the other lock-free launches (hogwild_grid): every wavefront holds up to
             // RING item rows at a time and the cells are uniform over the I items, so about waves * RING / I
@@ -842,12 +876,41 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
             const int ring = h->opt == CYMF_OPT_SGD ? 16 : 8;
             const int holders = getenv("CYMF_RELMF_HOLDERS") ? std::max(1, atoi(getenv("CYMF_RELMF_HOLDERS"))) : 4;
             const int64_t max_waves = std::max<int64_t>(64, std::min<int64_t>(256 * 12, (int64_t)holders * h->I / ring));
-            const int32_t upw = (int32_t)std::max<int64_t>(1, ((int64_t)h->U + max_waves - 1) / max_waves);
-            const int64_t waves = ((int64_t)h->U + upw - 1) / upw;
+            const int32_t upw = (int32_t)std::max<int64_t>(1, ((int64_t)my_users + max_waves - 1) / max_waves);
+            const int64_t waves = std::max<int64_t>(1, ((int64_t)my_users + upw - 1) / upw);
             CYMF_TRY(h->d_err.alloc(1));
             CYMF_TRY(h->d_err.zero(h->stream));
-            launch_relmf_step(h->K, h->opt, sd, h->d_uoff[b].p, h->d_items[b].p, h->U, upw, h->d_loss.p, h->d_err.p, (int)((waves + 3) / 4), h->stream);
-            CYMF_HIP(hipGetLastError());
+            if (!h->comm) {
+                launch_relmf_step(h->K, h->opt, sd, h->d_uoff[b].p, h->d_items[b].p, h->U, upw, h->d_loss.p, h->d_err.p, (int)((waves + 3) / 4), h->stream);
+                CYMF_HIP(hipGetLastError());
+            } else {
+                // sub-steps = ranges of turns (a user has about I draws: Poisson, so I + 6 sqrt(I) covers practically all; the
+                // last sub-step is open-ended and takes the stragglers), each followed by the exchange of the item deltas
+                const int32_t S = std::max(1, h->steps_per_epoch);
+                const int64_t turns = ((int64_t)(h->I + 6.0 * std::sqrt((double)h->I)) + 255) / 256 + 1;
+                const int world = comm_world(h->comm);
+                const int64_t nH = (int64_t)h->I * h->K;
+                const int with_acc = h->opt == CYMF_OPT_ADAGRAD ? 1 : 0;
+                double rho = 2.0 * h->lr * h->wd + 0.2 * h->lr;
+                if (h->opt == CYMF_OPT_ADAM) rho = 5.0 * h->lr;
+                const double a = std::pow(1.0 - std::min(0.5, rho), ((double)h->U / S) / world);   // U / S touches of an item per sub-step
+                const float scale = (float)(a < 1.0 - 1e-12 ? (1.0 - std::pow(a, world)) / (world * (1.0 - a)) : 1.0);
+                for (int32_t q = 0; q < S; ++q) {
+                    sd.turn_lo = turns * q / S;
+                    sd.turn_hi = q + 1 < S ? turns * (q + 1) / S : (int64_t)1 << 40;
+                    if (my_users > 0 && sd.turn_lo < sd.turn_hi) {
+                        launch_relmf_step(h->K, h->opt, sd, h->d_uoff[b].p, h->d_items[b].p, h->U, upw, h->d_loss.p, h->d_err.p, (int)((waves + 3) / 4), h->stream);
+                        CYMF_HIP(hipGetLastError());
+                    }
+                    hipLaunchKernelGGL(relmf_delta_kernel, dim3(ew_blocks(nH)), dim3(256), 0, h->stream, st.H.p ? reinterpret_cast<const float *>(st.H.p) : nullptr,
+                                       reinterpret_cast<const float *>(st.H0.p), h->d_snapH.p, h->d_snapA.p, h->d_xdelta.p, nH, with_acc);
+                    CYMF_HIP(hipGetLastError());
+                    CYMF_TRY(comm_allreduce_sum_f32(h->comm, h->d_xdelta.p, nH * (1 + with_acc), h->stream));
+                    hipLaunchKernelGGL(relmf_apply_kernel, dim3(ew_blocks(nH)), dim3(256), 0, h->stream, reinterpret_cast<float *>(st.H.p),
+                                       reinterpret_cast<float *>(st.H0.p), h->d_snapH.p, h->d_snapA.p, h->d_xdelta.p, scale, nH, with_acc);
+                    CYMF_HIP(hipGetLastError());
+                }
+            }
             CYMF_HIP(hipEventRecord(h->ev_step_done[b], h->stream));
             h->epoch_cursor++;
         }
@@ -954,6 +1017,19 @@ extern "C" int cymf_relmf_upload(cymf_relmf *h, const double *W, const double *H
     if (!h || !W || !H) return fail(CYMF_ERR_INVALID, "cymf_relmf_upload: bad arguments");
     CYMF_TRY(use_device(h->device));
     if (h->dtype == CYMF_F32) CYMF_TRY(relmf_upload(h, h->f32, W, H)); else CYMF_TRY(relmf_upload(h, h->f64, W, H));
+    if (h->comm) {
+        if (!h->step_path) return fail(CYMF_ERR_UNSUPPORTED, "cymf_relmf: a communicator needs the float32 throughput step path (K <= 128)");
+        const size_t nH = (size_t)h->I * h->K;
+        const bool acc = h->opt == CYMF_OPT_ADAGRAD;
+        CYMF_TRY(h->d_snapH.alloc(nH));
+        CYMF_TRY(h->d_xdelta.alloc(nH * (acc ? 2 : 1)));
+        CYMF_HIP(hipMemcpyAsync(h->d_snapH.p, h->f32.H.p, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        if (acc) {
+            CYMF_TRY(h->d_snapA.alloc(nH));
+            CYMF_HIP(hipMemcpyAsync(h->d_snapA.p, h->f32.H0.p, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        }
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+    }
     h->have_params = true;
     return 0;
 }
@@ -962,8 +1038,28 @@ extern "C" int cymf_relmf_download(cymf_relmf *h, double *W, double *H) {
     if (!h || !W || !H || !h->have_params) return fail(CYMF_ERR_INVALID, "cymf_relmf_download: bad arguments / no params");
     CYMF_TRY(use_device(h->device));
     const size_t nW = (size_t)h->U * h->K, nH = (size_t)h->I * h->K;
+    if (h->comm && h->dtype == CYMF_F32)   // every rank returns all user rows
+        CYMF_TRY(comm_allgatherv(h->comm, h->f32.W.p, h->user_bounds.data(), (int64_t)h->K * (int64_t)sizeof(float), h->stream));
     if (h->dtype == CYMF_F32) { CYMF_TRY(download_f64(h->f32.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f32.H, H, nH, h->stream)); }
     else { CYMF_TRY(download_f64(h->f64.W, W, nW, h->stream)); CYMF_TRY(download_f64(h->f64.H, H, nH, h->stream)); }
+    return 0;
+}
+
+extern "C" int cymf_relmf_set_steps_per_epoch(cymf_relmf *h, int32_t steps) {
+    if (!h || steps < 1) return fail(CYMF_ERR_INVALID, "cymf_relmf_set_steps_per_epoch: bad arguments");
+    h->steps_per_epoch = steps;
+    return 0;
+}
+
+extern "C" int cymf_relmf_attach_comm(cymf_relmf *h, cymf_comm *c, const int64_t *user_bounds) {
+    if (!h || !c || !user_bounds) return fail(CYMF_ERR_INVALID, "cymf_relmf_attach_comm: bad arguments");
+    if (h->have_params) return fail(CYMF_ERR_INVALID, "cymf_relmf_attach_comm must precede cymf_relmf_upload");
+    const int world = comm_world(c);
+    if (user_bounds[0] != 0 || user_bounds[world] != h->U) return fail(CYMF_ERR_INVALID, "cymf_relmf_attach_comm: bounds must run from 0 to U");
+    for (int r = 0; r < world; ++r)
+        if (user_bounds[r] > user_bounds[r + 1]) return fail(CYMF_ERR_INVALID, "cymf_relmf_attach_comm: bounds not monotone");
+    h->comm = c;
+    h->user_bounds.assign(user_bounds, user_bounds + world + 1);
     return 0;
 }
 

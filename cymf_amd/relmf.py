@@ -22,7 +22,10 @@ class RelMF(object):
             raise Exception(f"{self.optimizer} is invalid.")   # cymf/relmf.pyx:64-65
 
     def fit(self, X, num_epochs=10, num_threads=1, valid_evaluator=None, early_stopping=False, verbose=False,
-            *, mode=None, dtype=None, device=0):
+            *, mode=None, dtype=None, device=0, comm=None, steps_per_epoch=None):
+        """cymf/relmf.pyx:67-101.  comm (a dist.Comm, one process per GPU, throughput mode): users are cut into equal ranges
+        over the ranks (every user has about I draws per epoch), the item table is replicated and synchronised after each
+        of the steps_per_epoch sub-steps (default 4 per rank); every rank ends with the same full W and H."""
         if X is None:
             raise ValueError()
         if sparse.issparse(X):                                   # cymf/relmf.pyx:79-81: densify
@@ -38,8 +41,15 @@ class RelMF(object):
             _host.init_factors(self, U, I, self.num_components)
         mode = _host.pick_mode(mode, num_threads)
         dtype = _host.pick_dtype(dtype, mode)
+        bounds = None
+        if comm is not None:
+            bounds = np.round(np.linspace(0, U, comm.world + 1)).astype(np.int64)
+            device = comm.device
+            if steps_per_epoch is None:
+                steps_per_epoch = 4 * comm.world
         trainer = RelMfTrainer(U, I, self.num_components, self.optimizer, self.learning_rate, self.weight_decay,
-                               self.clip_value, dtype=dtype, mode=mode, device=device)
+                               self.clip_value, dtype=dtype, mode=mode, device=device, comm=comm, user_bounds=bounds,
+                               steps_per_epoch=steps_per_epoch or 1)
         try:
             trainer.set_data(X, propensities)
             trainer.upload(self.W, self.H)
@@ -48,7 +58,10 @@ class RelMF(object):
             width = len(str(num_epochs))
             self.losses = []
             for epoch in range(num_epochs):
-                self.losses.append(trainer.epochs(1)[0])
+                loss = trainer.epochs(1)[0]
+                if comm is not None:   # the loss of the whole job (each rank sums over its users' draws)
+                    loss = float(comm.allreduce(np.array([loss], dtype=np.float32))[0])
+                self.losses.append(loss)
                 desc = f"EPOCH={epoch+1:{width}} "
                 if self.valid_evaluator:
                     trainer.download(self.W, self.H)
@@ -66,12 +79,17 @@ class RelMF(object):
 
 class RelMfTrainer:
     def __init__(self, U, I, K, optimizer="adam", lr=0.001, wd=0.01, clip=0.1, seed=1234, dtype="float32",
-                 mode="exact", device=0):
+                 mode="exact", device=0, comm=None, user_bounds=None, steps_per_epoch=1):
         self.L = _lib.lib()
         self.U, self.I, self.K = int(U), int(I), int(K)
         self.h = C.c_void_p()
         _lib.check(self.L.cymf_relmf_create(C.byref(self.h), self.U, self.I, self.K, _lib.OPT_IDS[optimizer], lr, wd,
                                             clip, seed, _lib.DTYPE_IDS[dtype], _lib.MODE_IDS[mode], device))
+        self.comm = comm
+        if comm is not None:
+            b = np.ascontiguousarray(user_bounds, dtype=np.int64)
+            _lib.check(self.L.cymf_relmf_attach_comm(self.h, comm.h, _lib.ptr(b)))
+            _lib.check(self.L.cymf_relmf_set_steps_per_epoch(self.h, int(steps_per_epoch)))
 
     def set_data(self, X, propensities):
         X, p = _lib.f64c(X), _lib.f64c(propensities)

@@ -143,6 +143,11 @@ int cymf_relmf_upload(cymf_relmf *h, const double *W, const double *H);
 int cymf_relmf_download(cymf_relmf *h, double *W, double *H);
 int cymf_relmf_epochs(cymf_relmf *h, int32_t n_epochs, double *loss_out);   /* loss_out[e] = sum of loss[l], :150-152 */
 int cymf_relmf_destroy(cymf_relmf *h);
+/* Multi-GPU: users sharded by the given ranges (every rank draws the whole cell stream and works through its own users), item
+ * table replicated, its deltas all-reduced after each of the steps_per_epoch sub-steps; download() gathers the user rows.
+ * float32 throughput mode.  attach before cymf_relmf_upload. */
+int cymf_relmf_set_steps_per_epoch(cymf_relmf *h, int32_t steps);
+int cymf_relmf_attach_comm(cymf_relmf *h, cymf_comm *c, const int64_t *user_bounds);
 
 /* ---------------------------------------------------------------- GloVe
  * replaces GloVe._fit_glove, cymf/glove.pyx:117-162 (loop :149-156) with
