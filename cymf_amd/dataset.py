@@ -64,3 +64,76 @@ class MovieLens(ImplicitFeedbackDataset):
             if x not in x2index:
                 x2index[x] = len(x2index)
         return column.map(lambda x: x2index[x])
+
+
+class YahooMusic(ImplicitFeedbackDataset):
+    """cymf/dataset/yahoomusic.py:18-61 (Yahoo! R3).  The reference also only reads local files here (:23-26, it prints
+    where to get them and exits); this one raises FileNotFoundError instead of ending the interpreter.  Ids are 1-based in
+    the files (:31-32, :40-41); the matrix shape comes from the TRAIN file's largest ids (:45-46), so a test pair outside
+    it raises in to_matrix exactly as the reference's would; the train file is split 90/10 into train/valid with
+    random_state=12345 (:48), the test file is used whole."""
+
+    TRAIN_FILE = "ydata-ymusic-rating-study-v1_0-train.txt"
+    TEST_FILE = "ydata-ymusic-rating-study-v1_0-test.txt"
+
+    def __init__(self, min_rating=4.0, under_sampling=None, root=None):
+        super().__init__("yahoomusic", min_rating, root)
+        import pandas as pd
+        from sklearn.model_selection import train_test_split
+        frames = []
+        for name in (self.TRAIN_FILE, self.TEST_FILE):
+            path = self.dir_path.joinpath(name)
+            if not path.exists():
+                raise FileNotFoundError(f"{path} not found: get the R3 dataset from webscope.sandbox.yahoo.com and put it under {self.dir_path}")
+            df = pd.read_csv(path, sep="\t", names=["user", "item", "rating"])
+            df["user"] -= 1
+            df["item"] -= 1
+            df = df[df["rating"] >= min_rating].copy()
+            df["rating"] = 1.0
+            frames.append(df)
+        self.df_train, self.df_test = frames
+        self.num_user = int(self.df_train.user.max()) + 1
+        self.num_item = int(self.df_train.item.max()) + 1
+        self.df_train, self.df_valid = train_test_split(self.df_train, test_size=0.1, random_state=12345)
+        self.train = self.to_matrix(self.df_train)
+        self.valid = self.to_matrix(self.df_valid)
+        self.test = self.to_matrix(self.df_test)
+        self.train_size = self.train.nnz
+        self.valid_size = self.valid.nnz
+        self.test_size = self.test.nnz
+
+
+class CooccurrrenceDataset(object):
+    """cymf/dataset/cooccurrence.py:18-32 (the class name keeps the reference's spelling)."""
+
+    def __init__(self, fname, min_count=5, window_size=10, root=None):
+        self.root = Path(root) if root is not None else Path.home().joinpath(".cymf")
+        self.path = self.root.joinpath(fname)
+        self.min_count = min_count
+        self.window_size = window_size
+
+    def vocab_size(self):
+        raise NotImplementedError()
+
+
+class Text8(CooccurrrenceDataset):
+    """cymf/dataset/text8.py:20-53, minus the download: reads `root/text8` (lang="en") or `root/ja.text8` (lang="ja"),
+    or unpacks `root/<name>.zip` if only the archive is there (:45-46), then builds the co-occurrence matrix with
+    cymf_amd.glove.read_text (:48)."""
+
+    def __init__(self, lang="en", min_count=5, window_size=10, root=None):
+        if lang not in ("en", "ja"):
+            raise ValueError("An argument 'lang' must be 'en' or 'ja'.")
+        super().__init__("text8" if lang == "en" else "ja.text8", min_count, window_size, root)
+        if not self.path.exists():
+            zip_path = self.path.parent.joinpath(self.path.name + ".zip")
+            if not zip_path.exists():
+                raise FileNotFoundError(f"{self.path} (or {zip_path.name}) not found: this loader never downloads")
+            import zipfile
+            with zipfile.ZipFile(zip_path) as zf:
+                zf.extractall(self.path.parent)
+        from .glove import read_text
+        self.X, self.i2w = read_text(str(self.path), self.min_count, self.window_size)
+
+    def vocab_size(self):
+        return len(self.i2w)

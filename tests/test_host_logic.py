@@ -190,6 +190,60 @@ def test_movielens_local_loader(tmp_path):
     assert sorted(zip(te.user, te.item)) == sorted(zip(*ds.test.nonzero()))
 
 
+def test_yahoomusic_local_loader(tmp_path):
+    pd = pytest.importorskip("pandas")
+    sk = pytest.importorskip("sklearn.model_selection")
+    from cymf_amd.dataset import YahooMusic
+    with pytest.raises(FileNotFoundError):
+        YahooMusic(root=tmp_path)                                # cymf/dataset/yahoomusic.py:23-26 exits; this one raises
+    rs = np.random.RandomState(1)
+    d = tmp_path / "yahoomusic"
+    d.mkdir()
+    frames = {}
+    for name, n in ((YahooMusic.TRAIN_FILE, 4000), (YahooMusic.TEST_FILE, 600)):
+        df = pd.DataFrame({"user": rs.randint(1, 301, n), "item": rs.randint(1, 101, n), "rating": rs.randint(1, 6, n)})
+        df = df.drop_duplicates(["user", "item"])
+        if name == YahooMusic.TRAIN_FILE:                        # the shape comes from the train file's largest ids (:45-46)
+            df = pd.concat([df, pd.DataFrame({"user": [300], "item": [100], "rating": [5]})]).drop_duplicates(["user", "item"], keep="last")
+        df.to_csv(d / name, sep="\t", header=False, index=False)
+        frames[name] = df
+    ds = YahooMusic(root=tmp_path)
+    assert ds.train.shape == ds.valid.shape == ds.test.shape == (300, 100)
+    tr_pos = frames[YahooMusic.TRAIN_FILE]
+    tr_pos = tr_pos[tr_pos.rating >= 4]
+    te_pos = frames[YahooMusic.TEST_FILE]
+    te_pos = te_pos[te_pos.rating >= 4]
+    assert ds.train_size + ds.valid_size == len(tr_pos) and ds.valid_size == int(np.ceil(0.1 * len(tr_pos)))
+    assert sorted(zip(te_pos.user - 1, te_pos.item - 1)) == sorted(zip(*ds.test.nonzero()))       # 1-based ids in the files
+    tr, va = sk.train_test_split(tr_pos, test_size=0.1, random_state=12345)
+    assert sorted(zip(va.user - 1, va.item - 1)) == sorted(zip(*ds.valid.nonzero()))
+    assert set(np.unique(ds.train.tocsr().data)) == {1.0}
+    ds5 = YahooMusic(min_rating=5.0, root=tmp_path)
+    assert ds5.train_size + ds5.valid_size == int((frames[YahooMusic.TRAIN_FILE].rating >= 5).sum())
+
+
+def test_text8_local_loader(tmp_path):
+    import zipfile
+    from cymf_amd.dataset import CooccurrrenceDataset, Text8
+    with pytest.raises(ValueError):
+        Text8(lang="de", root=tmp_path)                          # cymf/dataset/text8.py:28
+    with pytest.raises(FileNotFoundError):
+        Text8(root=tmp_path)                                     # never downloads
+    with pytest.raises(NotImplementedError):
+        CooccurrrenceDataset("x", root=tmp_path).vocab_size()    # cymf/dataset/cooccurrence.py:31-32
+    rs = np.random.RandomState(2)
+    words = [f"w{i}" for i in range(40)]
+    text = " ".join(words[min(39, int(z) - 1)] for z in rs.zipf(1.4, 5000))
+    with zipfile.ZipFile(tmp_path / "text8.zip", "w") as zf:     # only the archive present: unpacked next to it (:45-46)
+        zf.writestr("text8", text)
+    ds = Text8(min_count=4, window_size=5, root=tmp_path)
+    assert (tmp_path / "text8").exists()
+    M, i2w = read_text(str(tmp_path / "text8"), 4, 5)
+    assert ds.vocab_size() == len(i2w) == ds.X.shape[0] and (ds.X != M).nnz == 0 and ds.i2w == i2w
+    (tmp_path / "ja.text8").write_text(text)
+    assert Text8(lang="ja", min_count=4, window_size=5, root=tmp_path).vocab_size() == ds.vocab_size()
+
+
 def test_word_bounds_balance_pairs():
     rs = np.random.RandomState(0)
     central = rs.zipf(1.3, 200000) % 5000
