@@ -359,18 +359,37 @@ __device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &m
     bj += nt * bc;
     const f32x2 nt2 = {nt, nt};
     const f4 *cb4 = reinterpret_cast<const f4 *>(cb);
+    // The broadcast reads of the pivot row are issued a chunk (CH x 16 B) ahead of the FMAs that use them, into two
+    // alternating register sets: the pins below are `asm volatile`, which no load may cross, so a read issued next to its
+    // FMAs would be waited for on the spot (one full LDS latency per two v_pk_fma_f32 -- measured: the whole solve).
+    constexpr int G0 = (C + 1) / 4, G1 = K / 4, CH = 8, NCH = (G1 - G0 + CH - 1) / CH;
+    f4 buf[2][CH];
 #pragma unroll
-    for (int g = (C + 1) / 4; g < K / 4; ++g) {
-        const f4 v = cb4[g];
+    for (int u = 0; u < CH; ++u)
+        if (G0 + u < G1) buf[0][u] = cb4[G0 + u];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (4 * g + 2 * h + 1 > C) {
-                const f32x2 vh = {v[2 * h], v[2 * h + 1]};
-                a[2 * g + h] = __builtin_elementwise_fma(nt2, vh, a[2 * g + h]);
-                // the update is pinned to its column: left alone, the compiler sinks the FMAs of far columns
-                // to their first use and keeps every broadcast value alive for them (K=32 took 390 VGPRs)
-                asm volatile("" : "+v"(a[2 * g + h]));
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (G0 + (ch + 1) * CH + u < G1) buf[(ch + 1) & 1][u] = cb4[G0 + (ch + 1) * CH + u];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int g = G0 + ch * CH + u;
+            if (g < G1) {
+                const f4 v = buf[ch & 1][u];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (4 * g + 2 * h + 1 > C) {
+                        const f32x2 vh = {v[2 * h], v[2 * h + 1]};
+                        a[2 * g + h] = __builtin_elementwise_fma(nt2, vh, a[2 * g + h]);
+                        // the update is pinned to its column: left alone, the compiler sinks the FMAs of far columns
+                        // to their first use and keeps every broadcast value alive for them (K=32 took 390 VGPRs)
+                        asm volatile("" : "+v"(a[2 * g + h]));
+                    }
             }
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (C + 1 < K) gj_column<K, NW, C + 1>(a, bj, mypiv, j, colbuf, bbuf);
