@@ -406,32 +406,51 @@ __device__ __forceinline__ float solve_reg(f32x2 (&a)[K / 2], float bj, int j, f
 template <int T32> constexpr int tile_m(int t) { int m = 0; while (m < T32 && t >= T32 - m) { t -= T32 - m; ++m; } return m; }
 template <int T32> constexpr int tile_n(int t) { int m = 0; while (m < T32 && t >= T32 - m) { t -= T32 - m; ++m; } return m + t; }
 
-constexpr int WMF_STAGE = 32 * 33;   // one 32x32 tile, odd stride
+constexpr int WMF_STAGE_LD = 36;                  // stride of a staged tile row: 16-byte aligned rows, conflict-free ds_read_b128
+constexpr int WMF_STAGE = 32 * WMF_STAGE_LD;      // one 32x32 tile
 
 template <int T32, int NW>
 constexpr size_t wmf_reg_smem() { return sizeof(float) * ((size_t)NW * WMF_STAGE + 4 * 64 * NW + 32 * T32 + 2 * NW + 4); }
 
 // Round Q of the layout change: every wave stages its Q-th tile, then every lane takes what belongs to its
 // row out of the NW staged tiles.  Template recursion over rounds and tiles: the tile coordinates of a staged
-// tile must be compile-time constants, they select the registers a[32 n + e] the values are added to.
+// tile must be compile-time constants, they select the registers a[32 n + e] the values go to.
+// Lane j (row block jb = j / 32) gets column block c of its row from exactly ONE tile, (min(jb,c), max(jb,c)) -- its row
+// jl when jb is the tile's row block, its column jl (the transpose) otherwise -- so the take is an assignment: the row
+// registers come to life block by block while the accumulators die tile by tile, and the two never have to be held
+// together (holding all of both cost 450 spilled VGPRs per lane and row at K=128).  A wave skips the parts of a tile
+// none of its row blocks uses (wave-uniform branch); inside, a per-lane select keeps the other block's lanes unchanged.
+#define SKIP_OK(blk) true
 template <int T32, int NW, int W, int Q>
-__device__ __forceinline__ void stage_take(f32x2 (&a)[16 * T32], const float *stage, int jb, int jl) {
+__device__ __forceinline__ void stage_take(f32x2 (&a)[16 * T32], const float *stage, int jb, int jl, int wave) {
+    using f4 = __attribute__((ext_vector_type(4))) float;
     constexpr int NT = T32 * (T32 + 1) / 2;
     constexpr int t = W + NW * Q;
     if constexpr (t < NT) {
         constexpr int m = tile_m<T32>(t), n = tile_n<T32>(t);
         const float *st = stage + W * WMF_STAGE;
-        // branch-free (a branch around updates of a register subset costs a copy of the whole row at the join)
-        const float hit_m = jb == m ? 1.0f : 0.0f;
+        if (SKIP_OK(m)) {
+            const bool hit = jb == m;
+            const f4 *row = reinterpret_cast<const f4 *>(st + jl * WMF_STAGE_LD);
 #pragma unroll
-        for (int e = 0; e < 32; ++e) a[16 * n + e / 2][e & 1] += hit_m * st[jl * 33 + e];
+            for (int g = 0; g < 8; ++g) {
+                const f4 v = row[g];
+                a[16 * n + 2 * g] = hit ? f32x2{v[0], v[1]} : a[16 * n + 2 * g];
+                a[16 * n + 2 * g + 1] = hit ? f32x2{v[2], v[3]} : a[16 * n + 2 * g + 1];
+            }
+        }
         if constexpr (m != n) {             // the mirrored block reads the tile's transpose
-            const float hit_n = jb == n ? 1.0f : 0.0f;
+            if (SKIP_OK(n)) {
+                const bool hit = jb == n;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) a[16 * m + e / 2][e & 1] += hit_n * st[e * 33 + jl];
+                for (int e = 0; e < 16; ++e) {
+                    const f32x2 v = {st[2 * e * WMF_STAGE_LD + jl], st[(2 * e + 1) * WMF_STAGE_LD + jl]};
+                    a[16 * m + e] = hit ? v : a[16 * m + e];
+                }
+            }
         }
     }
-    if constexpr (W + 1 < NW) stage_take<T32, NW, W + 1, Q>(a, stage, jb, jl);
+    if constexpr (W + 1 < NW) stage_take<T32, NW, W + 1, Q>(a, stage, jb, jl, wave);
 }
 
 template <int T32, int NW, int Q, int TPW>
@@ -447,10 +466,10 @@ __device__ __forceinline__ void stage_rounds(f32x2 (&a)[16 * T32], const f32x16 
             if (lh == 0) bvec[32 * tm[Q] + li] = tot * weight;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[Q][r] * (weight - 1.0f);
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lh) * WMF_STAGE_LD + li] = acc[Q][r] * (weight - 1.0f);
     }
     group_sync<NW>();
-    stage_take<T32, NW, 0, Q>(a, stage, jb, jl);
+    stage_take<T32, NW, 0, Q>(a, stage, jb, jl, wave);
     if constexpr (Q + 1 < TPW) stage_rounds<T32, NW, Q + 1, TPW>(a, acc, bsum, tm, tn, stage, bvec, weight, jb, jl, wave, li, lh);
 }
 
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
     float *colbuf = stage + ((NW * WMF_STAGE + 3) & ~3);   // [2][64 NW], 16-byte aligned
     float *bbuf = colbuf + 2 * 64 * NW;                    // [2][64 NW]
     float *bvec = bbuf + 2 * 64 * NW;                      // [K]
-    const int tid = threadIdx.x, lane = tid & 63, wave = NW == 1 ? 0 : tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
 
     for (int32_t i = blockIdx.x; i < rows; i += gridDim.x) {
@@ -489,14 +508,23 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
         f32x16 acc[TPW];
         float bsum[TPW];
         int tm[TPW], tn[TPW];
+        // the accumulators start from the tile of A0 = YtY + lambda I, pre-divided by (w - 1): what is staged later,
+        // acc (w - 1), is then the finished A = A0 + (w - 1) G and the row registers never hold A0 beside the tiles
+        const float inv_w1 = 1.0f / (weight - 1.0f);             // (the host sends w == 1 to the other kernel)
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            acc[q] = (f32x16)(0.0f);
             bsum[q] = 0.0f;
             int m = 0, rem = wave + NW * q;
             while (m < T32 && rem >= T32 - m) { rem -= T32 - m; ++m; }
             tm[q] = m;
             tn[q] = m + rem;
+            if (wave + NW * q < NT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[q][r] = A0[(size_t)(32 * tm[q] + (r & 3) + 8 * (r >> 2) + 4 * lh) * K + 32 * tn[q] + li] * inv_w1;
+            } else {
+                acc[q] = (f32x16)(0.0f);
+            }
         }
         // 64 gathered rows per batch; each of the T32 32-column chunks of a gathered row is loaded once per
         // step and feeds every tile that uses it (tile (m, n) multiplies chunk m by chunk n)
@@ -537,16 +565,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
         const int jr = j < K ? j : 0;
         const int jb = jr >> 5, jl = jr & 31;
         f32x2 a[K / 2];
-        {
-            using f4 = __attribute__((ext_vector_type(4))) float;
-            const f4 *a0 = reinterpret_cast<const f4 *>(A0 + (size_t)jr * K);
 #pragma unroll
-            for (int g = 0; g < K / 4; ++g) {
-                const f4 v = a0[g];
-                a[2 * g] = f32x2{v[0], v[1]};
-                a[2 * g + 1] = f32x2{v[2], v[3]};
-            }
-        }
+        for (int g = 0; g < K / 2; ++g) a[g] = f32x2{0.0f, 0.0f};   // (constants: folded into the first select of each block)
         stage_rounds<T32, NW, 0, TPW>(a, acc, bsum, tm, tn, stage, bvec, weight, jb, jl, wave, li, lh);
         group_sync<NW>();
         const float x = probe == 1 ? a[0][0] + bvec[jr] : solve_reg<K, NW>(a, bvec[jr], j, colbuf, bbuf);   // (1: timing probe, no solve)
@@ -700,7 +720,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, my_rows, \
                                ip, ix, Xf, Yf, Gf, (float)h->weight, h->long_threshold, segs, nseg, h->d_scratch.p);        \
         if (my_rows <= 0) {                                                                                                 \
-        } else if (h->reg_solve) {                                                                                          \
+        } else if (h->reg_solve && h->weight != 1.0) {                                                                      \
             constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                        \
             const size_t smem_r = wmf_reg_smem<T32_, NW_>();                                                                \
             CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_>, smem_r));                                                     \
