@@ -403,8 +403,10 @@ __device__ __forceinline__ float solve_reg(f32x2 (&a)[K / 2], float bj, int j, f
 }
 
 // t-th pair (m <= n) of the row-major upper triangle of a T32 x T32 tile grid
-template <int T32> constexpr int tile_m(int t) { int m = 0; while (m < T32 && t >= T32 - m) { t -= T32 - m; ++m; } return m; }
-template <int T32> constexpr int tile_n(int t) { int m = 0; while (m < T32 && t >= T32 - m) { t -= T32 - m; ++m; } return m + t; }
+// (column by column: the last column block of the row registers comes to life only with the last T32 tiles, while most of the
+// accumulators are already gone -- the order of the layout change is what bounds the register peak)
+constexpr int tile_n(int t) { int n = 0; while ((n + 1) * (n + 2) / 2 <= t) ++n; return n; }
+constexpr int tile_m(int t) { return t - tile_n(t) * (tile_n(t) + 1) / 2; }
 
 constexpr int WMF_STAGE_LD = 36;                  // stride of a staged tile row: 16-byte aligned rows, conflict-free ds_read_b128
 constexpr int WMF_STAGE = 32 * WMF_STAGE_LD;      // one 32x32 tile
@@ -420,16 +422,15 @@ constexpr size_t wmf_reg_smem() { return sizeof(float) * ((size_t)NW * WMF_STAGE
 // registers come to life block by block while the accumulators die tile by tile, and the two never have to be held
 // together (holding all of both cost 450 spilled VGPRs per lane and row at K=128).  A wave skips the parts of a tile
 // none of its row blocks uses (wave-uniform branch); inside, a per-lane select keeps the other block's lanes unchanged.
-#define SKIP_OK(blk) true
 template <int T32, int NW, int W, int Q>
 __device__ __forceinline__ void stage_take(f32x2 (&a)[16 * T32], const float *stage, int jb, int jl, int wave) {
     using f4 = __attribute__((ext_vector_type(4))) float;
     constexpr int NT = T32 * (T32 + 1) / 2;
     constexpr int t = W + NW * Q;
     if constexpr (t < NT) {
-        constexpr int m = tile_m<T32>(t), n = tile_n<T32>(t);
+        constexpr int m = tile_m(t), n = tile_n(t);
         const float *st = stage + W * WMF_STAGE;
-        if (SKIP_OK(m)) {
+        {
             const bool hit = jb == m;
             const f4 *row = reinterpret_cast<const f4 *>(st + jl * WMF_STAGE_LD);
 #pragma unroll
@@ -440,37 +441,59 @@ __device__ __forceinline__ void stage_take(f32x2 (&a)[16 * T32], const float *st
             }
         }
         if constexpr (m != n) {             // the mirrored block reads the tile's transpose
-            if (SKIP_OK(n)) {
-                const bool hit = jb == n;
+            const bool hit = jb == n;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const f32x2 v = {st[2 * e * WMF_STAGE_LD + jl], st[(2 * e + 1) * WMF_STAGE_LD + jl]};
-                    a[16 * m + e] = hit ? v : a[16 * m + e];
-                }
+            for (int e = 0; e < 16; ++e) {
+                const f32x2 v = {st[2 * e * WMF_STAGE_LD + jl], st[(2 * e + 1) * WMF_STAGE_LD + jl]};
+                a[16 * m + e] = hit ? v : a[16 * m + e];
             }
         }
     }
     if constexpr (W + 1 < NW) stage_take<T32, NW, W + 1, Q>(a, stage, jb, jl, wave);
 }
 
-template <int T32, int NW, int Q, int TPW>
-__device__ __forceinline__ void stage_rounds(f32x2 (&a)[16 * T32], const f32x16 (&acc)[TPW], const float (&bsum)[TPW],
-                                             const int (&tm)[TPW], const int (&tn)[TPW], float *stage, float *bvec,
-                                             float weight, int jb, int jl, int wave, int li, int lh) {
+// Every wave holds a partial sum of EVERY tile (the gathered rows are dealt to the waves step by step, see the kernel):
+// wave 0 writes its partials of the round's NW tiles into the stage, then the other wave adds its own (plain read-add-write,
+// nobody else touches the stage in that phase), then all lanes take.  (ds_add_f32 instead of the read-add-write was tried:
+// ~700 cycles per wave instruction, 6 ms per K=128 user sweep.  A second stage region per wave, summed by the take, doubles
+// the take's reads in flight and with them the register peak: 940 spilled VGPRs.)
+template <int T32, int NW, int PH, int Q>
+__device__ __forceinline__ void stage_put(const f32x16 (&acc)[T32 * (T32 + 1) / 2], const float (&bsum)[T32], float *stage,
+                                          float *bvec, float weight, int li, int lh) {
+    constexpr int NT = T32 * (T32 + 1) / 2;
+#pragma unroll
+    for (int W = 0; W < NW; ++W) {
+        const int t = NW * Q + W;
+        if (t < NT) {
+            const int m = tile_m(t), n = tile_n(t);
+            float *st = stage + W * WMF_STAGE;
+            if (m == n) {
+                const float tot = (bsum[m] + __shfl_xor(bsum[m], 32, 64)) * weight;
+                if (lh == 0) bvec[32 * m + li] = PH == 0 ? tot : bvec[32 * m + li] + tot;
+            }
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = PH == 0 ? 0.0f : st[((r & 3) + 8 * (r >> 2) + 4 * lh) * WMF_STAGE_LD + li];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                st[((r & 3) + 8 * (r >> 2) + 4 * lh) * WMF_STAGE_LD + li] = __builtin_fmaf(acc[t][r], weight - 1.0f, old[r]);
+        }
+    }
+}
+
+template <int T32, int NW, int Q>
+__device__ __forceinline__ void stage_rounds(f32x2 (&a)[16 * T32], const f32x16 (&acc)[T32 * (T32 + 1) / 2], const float (&bsum)[T32],
+                                             float *stage, float *bvec, float weight, int jb, int jl, int wave, int li, int lh) {
     constexpr int NT = T32 * (T32 + 1) / 2;
     group_sync<NW>();   // the stage (and, first round, the previous row's column buffers / bvec) is free
-    if (wave + NW * Q < NT) {
-        float *st = stage + wave * WMF_STAGE;
-        if (tm[Q] == tn[Q]) {
-            const float tot = bsum[Q] + __shfl_xor(bsum[Q], 32, 64);
-            if (lh == 0) bvec[32 * tm[Q] + li] = tot * weight;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * lh) * WMF_STAGE_LD + li] = acc[Q][r] * (weight - 1.0f);
+    if (wave == 0) stage_put<T32, NW, 0, Q>(acc, bsum, stage, bvec, weight, li, lh);
+    if constexpr (NW > 1) {
+        group_sync<NW>();
+        if (wave != 0) stage_put<T32, NW, 1, Q>(acc, bsum, stage, bvec, weight, li, lh);
     }
     group_sync<NW>();
     stage_take<T32, NW, 0, Q>(a, stage, jb, jl, wave);
-    if constexpr (Q + 1 < TPW) stage_rounds<T32, NW, Q + 1, TPW>(a, acc, bsum, tm, tn, stage, bvec, weight, jb, jl, wave, li, lh);
+    if constexpr (NW * (Q + 1) < NT) stage_rounds<T32, NW, Q + 1>(a, acc, bsum, stage, bvec, weight, jb, jl, wave, li, lh);
 }
 
 // One row per workgroup of NW wavefronts (K = 32*T32 <= 64*NW).  The Gramian tiles are built as in
@@ -485,9 +508,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
                                                              float weight, int32_t long_threshold, int probe) {
     constexpr int K = 32 * T32;
     constexpr int NT = T32 * (T32 + 1) / 2;
-    constexpr int TPW = (NT + NW - 1) / NW;
     extern __shared__ unsigned char smem_raw[];
-    float *stage = reinterpret_cast<float *>(smem_raw);   // [NW][32][33]
+    float *stage = reinterpret_cast<float *>(smem_raw);   // [NW][32][WMF_STAGE_LD]
     float *colbuf = stage + ((NW * WMF_STAGE + 3) & ~3);   // [2][64 NW], 16-byte aligned
     float *bbuf = colbuf + 2 * 64 * NW;                    // [2][64 NW]
     float *bvec = bbuf + 2 * 64 * NW;                      // [K]
@@ -505,25 +527,29 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
         }
         if (long_threshold > 0 && p1 - p0 > long_threshold) continue;   // built from segments
         if (probe == 2) p1 = p0;                                         // timing probe: no gather, no MFMA
-        f32x16 acc[TPW];
-        float bsum[TPW];
-        int tm[TPW], tn[TPW];
-        // the accumulators start from the tile of A0 = YtY + lambda I, pre-divided by (w - 1): what is staged later,
-        // acc (w - 1), is then the finished A = A0 + (w - 1) G and the row registers never hold A0 beside the tiles
+        // Every wave accumulates EVERY tile, over its share of the gathered rows (the k=2 MFMA steps are dealt to the waves in
+        // turn): a gathered row is read from memory by one wave only -- with the tiles dealt out instead, both waves of a K=128
+        // row read all of it, and the gather (L2 misses into a 14-70 MB table) is what bounds this phase.  The partial tiles meet
+        // in the LDS stage (stage_rounds).  Wave 0's accumulators start from the tile of A0 = YtY + lambda I, pre-divided by
+        // (w - 1): what is staged later, acc (w - 1), is then the finished A = A0 + (w - 1) G.
+        f32x16 acc[NT];
+        float bsum[T32];
         const float inv_w1 = 1.0f / (weight - 1.0f);             // (the host sends w == 1 to the other kernel)
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            bsum[q] = 0.0f;
-            int m = 0, rem = wave + NW * q;
-            while (m < T32 && rem >= T32 - m) { rem -= T32 - m; ++m; }
-            tm[q] = m;
-            tn[q] = m + rem;
-            if (wave + NW * q < NT) {
+        for (int m = 0; m < T32; ++m) bsum[m] = 0.0f;
+        {
+            int a0off = 4 * lh * K + li;                         // this lane's corner of every tile; the rest are constants
+            asm volatile("" : "+v"(a0off));                      // per row: 160 hoisted address pairs would live in scratch
+            const float *a0l = A0 + a0off;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[q][r] = A0[(size_t)(32 * tm[q] + (r & 3) + 8 * (r >> 2) + 4 * lh) * K + 32 * tn[q] + li] * inv_w1;
-            } else {
-                acc[q] = (f32x16)(0.0f);
+            for (int t = 0; t < NT; ++t) {
+                if (wave == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[t][r] = a0l[(32 * tile_m(t) + (r & 3) + 8 * (r >> 2)) * K + 32 * tile_n(t)] * inv_w1;
+                } else {
+                    acc[t] = (f32x16)(0.0f);
+                }
             }
         }
         // 64 gathered rows per batch; each of the T32 32-column chunks of a gathered row is loaded once per
@@ -533,12 +559,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
             const int32_t myidx = myp < p1 ? indices[myp] : -1;
             const int nb = p1 - pb < 64 ? p1 - pb : 64;
             const int steps = (nb + 1) >> 1;
-            for (int s0 = 0; s0 < steps; s0 += 8) {
+            for (int s0 = wave; s0 < steps; s0 += 8 * NW) {     // steps wave, wave + NW, ... (at most 32 per batch)
                 float ch[8][T32];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int32_t idx = __shfl(myidx, 2 * (s0 + u) + lh, 64);
-                    const bool ok = idx >= 0;
+                    const int32_t idx = __shfl(myidx, 2 * (s0 + NW * u) + lh, 64);
+                    const bool ok = idx >= 0 && s0 + NW * u < steps;
                     const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
 #pragma unroll
                     for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
@@ -546,18 +572,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
 #pragma unroll
-                    for (int q = 0; q < TPW; ++q) {
-                        if (wave + NW * q < NT) {
-                            float av = ch[u][0], bv = ch[u][0];
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
 #pragma unroll
-                            for (int m = 1; m < T32; ++m) {      // chunk select: compile-time for one wave per row
-                                av = tm[q] == m ? ch[u][m] : av;
-                                bv = tn[q] == m ? ch[u][m] : bv;
-                            }
-                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
-                            if (tm[q] == tn[q]) bsum[q] += av;
-                        }
-                    }
+                    for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
                 }
             }
         }
@@ -567,9 +585,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
         f32x2 a[K / 2];
 #pragma unroll
         for (int g = 0; g < K / 2; ++g) a[g] = f32x2{0.0f, 0.0f};   // (constants: folded into the first select of each block)
-        stage_rounds<T32, NW, 0, TPW>(a, acc, bsum, tm, tn, stage, bvec, weight, jb, jl, wave, li, lh);
+        stage_rounds<T32, NW, 0>(a, acc, bsum, stage, bvec, weight, jb, jl, wave, li, lh);
         group_sync<NW>();
-        const float x = probe == 1 ? a[0][0] + bvec[jr] : solve_reg<K, NW>(a, bvec[jr], j, colbuf, bbuf);   // (1: timing probe, no solve)
+        const float bj0 = bvec[jr];
+        const float x = probe == 1 ? a[0][0] + bj0 : solve_reg<K, NW>(a, bj0, j, colbuf, bbuf);   // (1: timing probe, no solve)
         if (j < K) X[(int64_t)i * K + j] = x;                  // wmf.pyx:170-171
     }
 }

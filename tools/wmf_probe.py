@@ -18,7 +18,7 @@ Xt = X.T.tocsr()
 for Kx in [int(k) for k in (sys.argv[1:] or ["64", "128"])]:
     rs = np.random.RandomState(4321)
     W, H = rs.uniform(-0.1, 0.1, (U, Kx)) / Kx, rs.uniform(-0.1, 0.1, (I, Kx)) / Kx
-    for probe in ("0", "1", "2"):
+    for probe in os.environ.get("PROBES", "0,1,2").split(","):
         os.environ["CYMF_WMF_PROBE"] = probe
         t = WmfTrainer(U, I, Kx, 10.0, 0.01, dtype="float32")
         t.set_data(X.indptr, X.indices, Xt.indptr, Xt.indices)
