@@ -405,7 +405,7 @@ __device__ __forceinline__ float solve_reg(f32x2 (&a)[K / 2], float bj, int j, f
 // t-th pair (m <= n) of the row-major upper triangle of a T32 x T32 tile grid
 // (column by column: the last column block of the row registers comes to life only with the last T32 tiles, while most of the
 // accumulators are already gone -- the order of the layout change is what bounds the register peak)
-constexpr int tile_n(int t) { int n = 0; while ((n + 1) * (n + 2) / 2 <= t) ++n; return n; }
+constexpr int tile_n(int t) { return (t >= 1) + (t >= 3) + (t >= 6); }   // T32 <= 4 (no loop: it has to fold inside `#pragma unroll` bodies)
 constexpr int tile_m(int t) { return t - tile_n(t) * (tile_n(t) + 1) / 2; }
 
 constexpr int WMF_STAGE_LD = 36;                  // stride of a staged tile row: 16-byte aligned rows, conflict-free ds_read_b128
@@ -593,6 +593,73 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
     }
 }
 
+// Segment of a long row (or of the identity list: YtY), 4 waves: as in wmf_row_reg_kernel every wave accumulates every tile
+// over its share of the k=2 steps (wave w takes steps w, w+4, ...), so a gathered row is fetched by ONE wave -- with the tiles
+// dealt to the waves (wmf_row_mfma_kernel<T32, true>, kept for CYMF_WMF_LDS_SOLVE) every wave fetched the chunks of its own
+// tiles, 20 chunk loads per gathered row pair where 4 suffice.  No LDS, no barrier; the partial tiles and column sums are
+// added to scratch[slot] (K*K + K floats) with float atomics, the mirrored block as well (the finish kernel and the readers of
+// YtY take the full matrix).
+template <int T32>
+__global__ __launch_bounds__(WMF_THREADS, 2) void wmf_seg_kernel(const int32_t *__restrict__ indices, const float *__restrict__ Y,
+                                                             const WmfSeg *__restrict__ segs, int32_t n_segs,
+                                                             float *__restrict__ scratch) {
+    constexpr int K = 32 * T32;
+    constexpr int NT = T32 * (T32 + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    for (int32_t item = blockIdx.x; item < n_segs; item += gridDim.x) {
+        const WmfSeg sg = segs[item];
+        const int32_t p0 = sg.begin, p1 = sg.end;
+        f32x16 acc[NT];
+        float bsum[T32];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x16)(0.0f);
+#pragma unroll
+        for (int m = 0; m < T32; ++m) bsum[m] = 0.0f;
+        for (int32_t pb = p0; pb < p1; pb += 64) {
+            const int32_t myp = pb + lane;
+            const int32_t myidx = myp < p1 ? indices[myp] : -1;
+            const int nb = p1 - pb < 64 ? p1 - pb : 64;
+            const int steps = (nb + 1) >> 1;                     // <= 32: one pass of 8 steps per wave
+            for (int s0 = wave; s0 < steps; s0 += 32) {          // (runs once; written as the loop of wmf_row_reg_kernel)
+                float ch[8][T32];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int32_t idx = __shfl(myidx, 2 * (s0 + 4 * u) + lh, 64);
+                    const bool ok = idx >= 0 && s0 + 4 * u < steps;
+                    const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
+#pragma unroll
+                    for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
+                }
+            }
+        }
+        float *G = scratch + (size_t)sg.slot * (K * K + K);
+#pragma unroll
+        for (int m = 0; m < T32; ++m) {
+            const float tot = bsum[m] + __shfl_xor(bsum[m], 32, 64);
+            if (lh == 0) atomicAdd(G + K * K + 32 * m + li, tot);
+        }
+        float *gd = G + 4 * lh * K + li, *gm = G + li * K + 4 * lh;   // this lane's corner of a tile / of its mirror image
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                atomicAdd(gd + (32 * tile_m(t) + rr) * K + 32 * tile_n(t), acc[t][r]);
+                if (tile_m(t) != tile_n(t)) atomicAdd(gm + 32 * tile_n(t) * K + 32 * tile_m(t) + rr, acc[t][r]);
+            }
+        }
+    }
+}
+
 // long rows: A = A0 + (w-1) G, b = w * sum, both from the scratch the segments accumulated
 __global__ __launch_bounds__(WMF_THREADS) void wmf_long_finish_kernel(int K, const int32_t *__restrict__ long_rows,
                                                                      float *__restrict__ X, const float *__restrict__ A0,
@@ -647,6 +714,7 @@ struct cymf_wmf {
     bool reg_solve = true;   // register-resident solve (wmf_row_reg_kernel); CYMF_WMF_LDS_SOLVE=1 selects the in-LDS one
     // rows with more than long_threshold entries are built from segments (MFMA path)
     int32_t long_threshold = 2048;
+    int32_t seg_len = 0;            // 0: default (see set_data); CYMF_WMF_SEG
     DevBuf<cymf::WmfSeg> d_segs[2];
     DevBuf<int32_t> d_long_rows[2];
     int32_t n_segs[2] = {0, 0}, n_long[2] = {0, 0};
@@ -697,10 +765,15 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             const int ns = h->n_gram_segs[g];
 #define WMF_GRAM_(T32_)                                                                                                       \
     do {                                                                                                                      \
-        CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, true>, smem));                                                           \
-        hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(ns), dim3(WMF_THREADS), smem, h->stream, 0, nullptr,        \
-                           h->d_iota.p, nullptr, reinterpret_cast<const float *>(Y), nullptr, 0.0f, 0, h->d_gram_segs[g].p, ns, \
-                           reinterpret_cast<float *>(st.G.p));                                                                \
+        if (h->reg_solve) {                                                                                                   \
+            hipLaunchKernelGGL((wmf_seg_kernel<T32_>), dim3(ns), dim3(WMF_THREADS), 0, h->stream, h->d_iota.p,                \
+                               reinterpret_cast<const float *>(Y), h->d_gram_segs[g].p, ns, reinterpret_cast<float *>(st.G.p)); \
+        } else {                                                                                                              \
+            CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, true>, smem));                                                       \
+            hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(ns), dim3(WMF_THREADS), smem, h->stream, 0, nullptr,    \
+                               h->d_iota.p, nullptr, reinterpret_cast<const float *>(Y), nullptr, 0.0f, 0, h->d_gram_segs[g].p, \
+                               ns, reinterpret_cast<float *>(st.G.p));                                                        \
+        }                                                                                                                     \
     } while (0)
             switch (K / 32) {
             case 1: WMF_GRAM_(1); break;
@@ -735,7 +808,10 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
     do {                                                                                                                    \
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, false>, smem));                                                        \
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, true>, smem));                                                         \
-        if (nseg > 0)   /* segments of the long rows first: the longest work starts earliest */                             \
+        if (nseg > 0 && h->reg_solve)   /* segments of the long rows first: the longest work starts earliest */             \
+            hipLaunchKernelGGL((wmf_seg_kernel<T32_>), dim3(grid_seg), dim3(WMF_THREADS), 0, h->stream, ix, Yf, segs, nseg,  \
+                               h->d_scratch.p);                                                                             \
+        else if (nseg > 0)                                                                                                  \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, my_rows, \
                                ip, ix, Xf, Yf, Gf, (float)h->weight, h->long_threshold, segs, nseg, h->d_scratch.p);        \
         if (my_rows <= 0) {                                                                                                 \
@@ -796,6 +872,7 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     }
     if (const char *e3 = getenv("CYMF_WMF_LDS_SOLVE")) h->reg_solve = !(e3[0] == '1');
     if (const char *e2 = getenv("CYMF_WMF_LONG")) h->long_threshold = std::max(64, atoi(e2));
+    if (const char *e3 = getenv("CYMF_WMF_SEG")) h->seg_len = std::max(64, atoi(e3));
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     *out = h;
@@ -868,8 +945,11 @@ extern "C" int cymf_wmf_set_data(cymf_wmf *h, const int32_t *indptr, const int32
             if (n <= h->long_threshold) continue;
             const int32_t slot = (int32_t)longs.size();
             longs.push_back(r);
-            for (int32_t b = ip[r]; b < ip[r + 1]; b += h->long_threshold)
-                segs.push_back(WmfSeg{slot, b, std::min(b + h->long_threshold, ip[r + 1]), 0});
+            // wmf_seg_kernel: every wave of a segment adds all tiles to the scratch, four times the atomics of the
+            // tile-dealing kernel per segment -- so its segments are four times as long
+            const int32_t seg_len = h->seg_len > 0 ? h->seg_len : (h->reg_solve ? 4 : 1) * h->long_threshold;
+            for (int32_t b = ip[r]; b < ip[r + 1]; b += seg_len)
+                segs.push_back(WmfSeg{slot, b, std::min(b + seg_len, ip[r + 1]), 0});
         }
         h->n_segs[side] = (int32_t)segs.size();
         h->n_long[side] = (int32_t)longs.size();

@@ -94,7 +94,8 @@ def test_wmf_with_world1_communicator_equals_plain_fit():
     a, b = WMF(64, 0.01, 10.0), WMF(64, 0.01, 10.0)
     a.fit(X, num_epochs=2, verbose=False)
     b.fit(X, num_epochs=2, verbose=False, comm=comm)
-    assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H)
+    # YtY and the long rows are summed with float atomics (order varies from run to run): equal to rounding, not bit for bit
+    assert np.linalg.norm(a.W - b.W) <= 1e-5 * np.linalg.norm(a.W) and np.linalg.norm(a.H - b.H) <= 1e-5 * np.linalg.norm(a.H)
     comm.close()
 
 
