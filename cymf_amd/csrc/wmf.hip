@@ -338,20 +338,16 @@ template <int K, int NW, int C>
 __device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &mypiv, int j, float *colbuf, float *bbuf) {
     using f4 = __attribute__((ext_vector_type(4))) float;
     constexpr int KP = 64 * NW;   // one slot per lane: idle lanes (j >= K) publish into slots nobody reads, no branch
-    float *cb = colbuf + (C & 1) * KP;
+    float *cb = colbuf + (C & 1) * KP;          // column C was published by the previous step (column 0: by solve_reg)
     const float raw = a[C / 2][C & 1];
-    cb[j] = raw;
     float d, bc;
+    group_sync<NW>();
     if constexpr (NW == 1) {      // the pivot row is a lane of this wave: no LDS round trip in front of the reciprocal
         d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, raw), C));
         bc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bj), C));
-        group_sync<NW>();
     } else {
-        float *bb = bbuf + (C & 1) * KP;
-        bb[j] = bj;
-        group_sync<NW>();
         d = cb[C];
-        bc = bb[C];
+        bc = (bbuf + (C & 1) * KP)[C];
     }
     const float rd = rcp_nr(d);
     const float nt = j == C ? 0.0f : -(raw * rd);
@@ -387,6 +383,12 @@ __device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &m
                         // the update is pinned to its column: left alone, the compiler sinks the FMAs of far columns
                         // to their first use and keeps every broadcast value alive for them (K=32 took 390 VGPRs)
                         asm volatile("" : "+v"(a[2 * g + h]));
+                        // look-ahead: the next pivot column is final as soon as its pair is updated -- it is published now
+                        // (other buffer), so that the LDS write and the wait for the other wave run under the remaining FMAs
+                        if (C + 1 < K && 2 * g + h == (C + 1) / 2) {
+                            (colbuf + ((C + 1) & 1) * KP)[j] = a[(C + 1) / 2][(C + 1) & 1];
+                            if (NW > 1) (bbuf + ((C + 1) & 1) * KP)[j] = bj;
+                        }
                     }
             }
         }
@@ -398,6 +400,8 @@ __device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &m
 template <int K, int NW>
 __device__ __forceinline__ float solve_reg(f32x2 (&a)[K / 2], float bj, int j, float *colbuf, float *bbuf) {
     float mypiv = 0.0f;   // 1 / pivot of this lane's row
+    colbuf[j] = a[0][0];  // column 0; every later column is published by the step before it
+    if (NW > 1) bbuf[j] = bj;
     gj_column<K, NW, 0>(a, bj, mypiv, j, colbuf, bbuf);
     return bj * mypiv;
 }
