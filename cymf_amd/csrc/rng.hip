@@ -171,6 +171,8 @@ __global__ __launch_bounds__(JUMP_THREADS) void mt_jump_kernel(const uint32_t *_
                                                               const uint32_t *__restrict__ poly) {
     extern __shared__ uint32_t x[];
     const int tid = threadIdx.x;
+    in_state += (size_t)blockIdx.x * MT_N;        // workgroup q: state q of the input run -> state q of the output run
+    out_state += (size_t)blockIdx.x * MT_N;
     for (int k = tid; k < MT_N; k += JUMP_THREADS) x[k] = in_state[k];
     __syncthreads();
     for (int b = 0; b < JUMP_DEG; b += 227) {     // lag 227: one data-parallel slab per barrier
@@ -335,6 +337,7 @@ int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel)
     parallel_ = parallel && rej_cap_ <= (1 << 19);   // beyond ~8 % rejections the one-workgroup walker serves (2 MB of list per chunk)
     if (parallel_) {
         CYMF_TRY(poly_.upload(MT_JUMP_POLY, MT_N, s));
+        CYMF_TRY(poly_wide_.upload(MT_JUMP_POLY_WIDE, MT_N, s));
         states_cap_ = 64;
         CYMF_TRY(states_.alloc((size_t)states_cap_ * MT_N));
         // chunk 0 starts at the seeded state (RngState begins with mt[624])
@@ -360,11 +363,24 @@ int DeviceRng::ensure_states(int64_t last_chunk, hipStream_t s) {
         std::swap(bigger.n, states_.n);
         states_cap_ = cap;
     }
-    while (states_known_ <= last_chunk) {   // chain of jumps, each ~0.1 ms on one CU
-        hipLaunchKernelGGL(mt_jump_kernel, dim3(1), dim3(JUMP_THREADS), JUMP_LDS_WORDS * sizeof(uint32_t), s,
-                           states_.p + (size_t)(states_known_ - 1) * MT_N, states_.p + (size_t)states_known_ * MT_N, poly_.p);
-        CYMF_HIP(hipGetLastError());
-        states_known_++;
+    // The first MT_JUMP_WIDE states come from a chain of single jumps (by one chunk, ~0.5 ms each on one CU); after that the
+    // next run of up to MT_JUMP_WIDE states follows from the run before it in ONE launch (jump by MT_JUMP_WIDE chunks, one
+    // workgroup per state).  The chain alone cost 11 ms per 100 M draws -- hidden under the step kernels on one GPU, but
+    // every rank of a sharded job generates the whole stream while its own steps shrink with the world size.
+    while (states_known_ <= last_chunk) {
+        if (states_known_ >= MT_JUMP_WIDE) {
+            const int n = (int)std::min<int64_t>(MT_JUMP_WIDE, last_chunk + 1 - states_known_);
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(n), dim3(JUMP_THREADS), JUMP_LDS_WORDS * sizeof(uint32_t), s,
+                               states_.p + (size_t)(states_known_ - MT_JUMP_WIDE) * MT_N, states_.p + (size_t)states_known_ * MT_N,
+                               poly_wide_.p);
+            CYMF_HIP(hipGetLastError());
+            states_known_ += n;
+        } else {
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(1), dim3(JUMP_THREADS), JUMP_LDS_WORDS * sizeof(uint32_t), s,
+                               states_.p + (size_t)(states_known_ - 1) * MT_N, states_.p + (size_t)states_known_ * MT_N, poly_.p);
+            CYMF_HIP(hipGetLastError());
+            states_known_++;
+        }
     }
     return 0;
 }

@@ -63,3 +63,13 @@ def test_chunked_jump_ahead_generator_vs_oracle(rng_range, n, skip):
     got = _lib.rng_fill_uniform(1234, rng_range, n, skip=skip)
     want = oracle.uniform_stream(1234, rng_range, n, skip=skip)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("rng_range,n,skip", [(100000, 300_000, 4_193_280 * 16 - 150_000), (100000, 2_000_000, 4_193_280 * 33 + 5),
+                                              (3706, 1_000_000, 4_193_280 * 47 - 500_000)])
+def test_wide_jump_states_vs_oracle(rng_range, n, skip):
+    """Chunk states from number 16 on come from the WIDE jump (16 chunks at once, tools/gen_mt_jump.py: MT_JUMP_POLY_WIDE), one
+    workgroup per state: draws across the chain/wide boundary, in the second wide run and past the third are the oracle's."""
+    got = _lib.rng_fill_uniform(1234, rng_range, n, skip=skip)
+    want = oracle.uniform_stream(1234, rng_range, n, skip=skip)
+    assert np.array_equal(got, want)

@@ -20,6 +20,8 @@ N, M = 624, 397
 DEG = 19937
 BLOCKS = 6720
 J = N * BLOCKS            # words per chunk of the raw stream (4,193,280)
+WIDE = 16                 # second polynomial: jump by WIDE chunks at once (the states of WIDE chunks follow from the WIDE before
+                          # them in ONE launch of WIDE workgroups instead of a chain of WIDE one-workgroup launches)
 
 
 def mt_words(state, count):
@@ -93,6 +95,10 @@ def main():
     phi = sum(((C >> i) & 1) << (L - i) for i in range(L + 1))
     g = power_of_t(J, phi)
     assert g.bit_length() <= DEG
+    gw = g
+    for _ in range(WIDE.bit_length() - 1):              # t^(WIDE J) = g^WIDE, WIDE a power of two: repeated squaring
+        gw = gf2_mod(gf2_square(gw), phi)
+    assert 1 << (WIDE.bit_length() - 1) == WIDE and gw == power_of_t(WIDE * J, phi)
 
     # self-check on another seed: jump by the XOR formula == brute force
     rs = np.random.RandomState(987654321)
@@ -110,7 +116,19 @@ def main():
     assert int(want[2]) == 624, want[2]
     assert (jumped[0] >> 31) == (int(key[0]) >> 31) and jumped[1:] == [int(v) for v in key[1:]], "jump self-check failed"
 
+    # the wide polynomial, checked the same way: WIDE * J outputs further on
+    jumped_w = [0] * N
+    for k in range(DEG):
+        if (gw >> k) & 1:
+            for m in range(N):
+                jumped_w[m] ^= seq[k + m]
+    for _ in range(WIDE - 1):
+        rs.randint(0, 2**32, size=J, dtype=np.uint64)
+    key = rs.get_state()[1].astype(np.uint32)
+    assert (jumped_w[0] >> 31) == (int(key[0]) >> 31) and jumped_w[1:] == [int(v) for v in key[1:]], "wide jump self-check failed"
+
     words = [(g >> (32 * i)) & 0xFFFFFFFF for i in range(N)]
+    words_w = [(gw >> (32 * i)) & 0xFFFFFFFF for i in range(N)]
     with open(out_path, "w") as f:
         f.write("// GENERATED by tools/gen_mt_jump.py -- do not edit.\n")
         f.write("// g(t) = t^J mod phi(t): MT19937 jump-ahead polynomial for J = 624 * %d raw words;\n" % BLOCKS)
@@ -121,6 +139,11 @@ def main():
         f.write("static const uint32_t MT_JUMP_POLY[624] = {\n")
         for i in range(0, N, 8):
             f.write("    " + ", ".join("0x%08xu" % w for w in words[i:i + 8]) + ",\n")
+        f.write("};\n")
+        f.write("constexpr int MT_JUMP_WIDE = %d;              // chunks per wide jump\n" % WIDE)
+        f.write("static const uint32_t MT_JUMP_POLY_WIDE[624] = {   // t^(MT_JUMP_WIDE * J) mod phi(t)\n")
+        for i in range(0, N, 8):
+            f.write("    " + ", ".join("0x%08xu" % w for w in words_w[i:i + 8]) + ",\n")
         f.write("};\n}  // namespace cymf\n")
     print("wrote", os.path.normpath(out_path), "J =", J, "popcount(g) =", bin(g).count("1"))
 
