@@ -41,7 +41,7 @@ class DeviceRng {
     int64_t rej_cap_ = 0;               // rejection-list entries per chunk
     // parallel mode
     uint64_t raw_pos_ = 0;              // next unconsumed raw word of the stream
-    DevBuf<uint32_t> poly_, poly_wide_, states_, tmp_, counts_, rej_, rej_cnt_;
+    DevBuf<uint32_t> poly_, states_, tmp_, counts_, rej_, rej_cnt_;
     int64_t states_cap_ = 0, states_known_ = 0;   // chunk start states [0, states_known_) are valid
     struct Pending {
         bool active = false;

@@ -336,8 +336,7 @@ int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel)
     while ((double)rej_cap_ < rej_per_chunk * 1.5 + 4096.0) rej_cap_ *= 2;
     parallel_ = parallel && rej_cap_ <= (1 << 19);   // beyond ~8 % rejections the one-workgroup walker serves (2 MB of list per chunk)
     if (parallel_) {
-        CYMF_TRY(poly_.upload(MT_JUMP_POLY, MT_N, s));
-        CYMF_TRY(poly_wide_.upload(MT_JUMP_POLY_WIDE, MT_N, s));
+        CYMF_TRY(poly_.upload(&MT_JUMP_POLYS[0][0], (size_t)MT_JUMP_LEVELS * MT_N, s));
         states_cap_ = 64;
         CYMF_TRY(states_.alloc((size_t)states_cap_ * MT_N));
         // chunk 0 starts at the seeded state (RngState begins with mt[624])
@@ -363,24 +362,21 @@ int DeviceRng::ensure_states(int64_t last_chunk, hipStream_t s) {
         std::swap(bigger.n, states_.n);
         states_cap_ = cap;
     }
-    // The first MT_JUMP_WIDE states come from a chain of single jumps (by one chunk, ~0.5 ms each on one CU); after that the
-    // next run of up to MT_JUMP_WIDE states follows from the run before it in ONE launch (jump by MT_JUMP_WIDE chunks, one
-    // workgroup per state).  The chain alone cost 11 ms per 100 M draws -- hidden under the step kernels on one GPU, but
-    // every rank of a sharded job generates the whole stream while its own steps shrink with the world size.
+    // Level l jumps by D = 4^l chunks: a run of up to D states follows from the run D chunks before it in ONE launch, one
+    // workgroup per state (~0.5 ms).  The largest D <= states_known_ is taken each time: 3 + 3 + 3 launches reach 64 states,
+    // 64 more per launch after that.  (A chain of single jumps, one launch per chunk, was the first version: 11 ms per 100 M
+    // draws -- hidden under the step kernels on one GPU, but every rank of a sharded job generates the whole stream while its
+    // own steps shrink with the world size.)
     while (states_known_ <= last_chunk) {
-        if (states_known_ >= MT_JUMP_WIDE) {
-            const int n = (int)std::min<int64_t>(MT_JUMP_WIDE, last_chunk + 1 - states_known_);
-            hipLaunchKernelGGL(mt_jump_kernel, dim3(n), dim3(JUMP_THREADS), JUMP_LDS_WORDS * sizeof(uint32_t), s,
-                               states_.p + (size_t)(states_known_ - MT_JUMP_WIDE) * MT_N, states_.p + (size_t)states_known_ * MT_N,
-                               poly_wide_.p);
-            CYMF_HIP(hipGetLastError());
-            states_known_ += n;
-        } else {
-            hipLaunchKernelGGL(mt_jump_kernel, dim3(1), dim3(JUMP_THREADS), JUMP_LDS_WORDS * sizeof(uint32_t), s,
-                               states_.p + (size_t)(states_known_ - 1) * MT_N, states_.p + (size_t)states_known_ * MT_N, poly_.p);
-            CYMF_HIP(hipGetLastError());
-            states_known_++;
-        }
+        int lvl = 0;
+        int64_t D = 1;
+        while (lvl + 1 < MT_JUMP_LEVELS && D * 4 <= states_known_) { D *= 4; ++lvl; }
+        const int n = (int)std::min<int64_t>(D, last_chunk + 1 - states_known_);
+        hipLaunchKernelGGL(mt_jump_kernel, dim3(n), dim3(JUMP_THREADS), JUMP_LDS_WORDS * sizeof(uint32_t), s,
+                           states_.p + (size_t)(states_known_ - D) * MT_N, states_.p + (size_t)states_known_ * MT_N,
+                           poly_.p + (size_t)lvl * MT_N);
+        CYMF_HIP(hipGetLastError());
+        states_known_ += n;
     }
     return 0;
 }

@@ -57,7 +57,7 @@ def test_range_limits_are_errors():
                                               (160_000_000, 3_000_000, 6_000_000), (300_000_000, 4_500_000, 0)])
 def test_chunked_jump_ahead_generator_vs_oracle(rng_range, n, skip):
     """skip + n >= 4M selects the parallel generator: chunk start states by the MT19937 jump-ahead
-    polynomial (tools/gen_mt_jump.py), one workgroup per 4,193,280-word chunk, ordered gather.
+    polynomials (tools/gen_mt_jump.py), one workgroup per 1,048,320-word chunk (4,193,280 = 4 chunks), ordered gather.
     range 4e7 rejects ~1% of the raw words; 1.6e8 (the U*I of a 20000 x 8000 RelMF problem) 3.1% and 3e8 2.2%:
     ~100 k rejections per chunk, the rejection list is sized from the range."""
     got = _lib.rng_fill_uniform(1234, rng_range, n, skip=skip)
@@ -68,8 +68,9 @@ def test_chunked_jump_ahead_generator_vs_oracle(rng_range, n, skip):
 @pytest.mark.parametrize("rng_range,n,skip", [(100000, 300_000, 4_193_280 * 16 - 150_000), (100000, 2_000_000, 4_193_280 * 33 + 5),
                                               (3706, 1_000_000, 4_193_280 * 47 - 500_000)])
 def test_wide_jump_states_vs_oracle(rng_range, n, skip):
-    """Chunk states from number 16 on come from the WIDE jump (16 chunks at once, tools/gen_mt_jump.py: MT_JUMP_POLY_WIDE), one
-    workgroup per state: draws across the chain/wide boundary, in the second wide run and past the third are the oracle's."""
+    """Chunk start states come from jumps by 1, 4, 16 and 64 chunks (tools/gen_mt_jump.py: MT_JUMP_POLYS), a run of states per
+    launch: draws across the boundary where the 64-chunk jumps take over (chunk 64 = 16 x 4,193,280 words), in the second
+    64-run and in the third are the oracle's."""
     got = _lib.rng_fill_uniform(1234, rng_range, n, skip=skip)
     want = oracle.uniform_stream(1234, rng_range, n, skip=skip)
     assert np.array_equal(got, want)
