@@ -424,8 +424,9 @@ constexpr size_t wmf_reg_smem() { return sizeof(float) * ((size_t)NW * WMF_STAGE
 // Lane j (row block jb = j / 32) gets column block c of its row from exactly ONE tile, (min(jb,c), max(jb,c)) -- its row
 // jl when jb is the tile's row block, its column jl (the transpose) otherwise -- so the take is an assignment: the row
 // registers come to life block by block while the accumulators die tile by tile, and the two never have to be held
-// together (holding all of both cost 450 spilled VGPRs per lane and row at K=128).  A wave skips the parts of a tile
-// none of its row blocks uses (wave-uniform branch); inside, a per-lane select keeps the other block's lanes unchanged.
+// together (holding all of both cost 450 spilled VGPRs per lane and row at K=128).  A per-lane select keeps the lanes of the
+// other row blocks unchanged.  (Skipping, by a wave-uniform branch, the parts of a tile none of the wave's row blocks uses was
+// tried: with the branch the compiler leaves half of the row in a stack array -- 7000 scratch accesses per row.)
 template <int T32, int NW, int W, int Q>
 __device__ __forceinline__ void stage_take(f32x2 (&a)[16 * T32], const float *stage, int jb, int jl, int wave) {
     using f4 = __attribute__((ext_vector_type(4))) float;
@@ -500,11 +501,10 @@ __device__ __forceinline__ void stage_rounds(f32x2 (&a)[16 * T32], const f32x16 
     if constexpr (NW * (Q + 1) < NT) stage_rounds<T32, NW, Q + 1>(a, acc, bsum, stage, bvec, weight, jb, jl, wave, li, lh);
 }
 
-// One row per workgroup of NW wavefronts (K = 32*T32 <= 64*NW).  The Gramian tiles are built as in
-// wmf_row_mfma_kernel (tiles dealt round-robin to the NW waves); each finished tile goes through a
-// 4 KB LDS stage once to turn the MFMA C layout into "lane j holds row j" (rows read the tile, the
-// mirrored block reads its transpose), and the system is solved in registers.  Little LDS and <= 168
-// VGPRs on purpose: the column steps are a latency chain, three waves per SIMD fill it.
+// One row per workgroup of NW wavefronts (K = 32*T32 <= 64*NW).  Every wave builds partial sums of all Gramian tiles over
+// its share of the gathered rows; the tiles go through a small LDS stage to turn the MFMA C layout into "lane j holds row j"
+// (rows read the tile, the mirrored block reads its transpose), and the system is solved in registers.  Little LDS and
+// <= 168 VGPRs at K <= 64 on purpose: the column steps are a latency chain, three waves per SIMD fill it.
 template <int T32, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(int32_t rows, const int32_t *__restrict__ indptr,
                                                              const int32_t *__restrict__ indices, float *__restrict__ X,
