@@ -1,5 +1,7 @@
 """Host-side mirror of the reference's class surface: argument validation,
 initialisation / shuffle parity, sharding helpers, metrics, co-occurrence builder.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -8,6 +10,8 @@ import oracle
 from conftest import golden
 from cymf_amd import BPR, WMF, GloVe, RelMF, _host, dist, metrics, synthetic
 from cymf_amd.glove import read_text
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_constructor_defaults_match_reference():
@@ -255,3 +259,28 @@ def test_word_bounds_balance_pairs():
         if world > 1:
             heaviest = np.bincount(central).max()
             assert max(per) <= len(central) / world + heaviest       # off by at most the word on the boundary
+
+
+def test_jump_polynomial_header_matches_its_generator():
+    """csrc/mt_jump_poly.h is generated (tools/gen_mt_jump.py): the committed coefficients are the ones the tool derives --
+    phi by Berlekamp-Massey on numpy's MT19937, g_0 = t^J mod phi, g_{l+1} = g_l^4 -- for the J the header states."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gen_mt_jump", os.path.join(ROOT, "tools", "gen_mt_jump.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = open(os.path.join(ROOT, "cymf_amd", "csrc", "mt_jump_poly.h")).read()
+    assert int(re.search(r"MT_JUMP_WORDS = (\d+)LL", text).group(1)) == gen.J == 624 * gen.BLOCKS
+    levels = int(re.search(r"MT_JUMP_LEVELS = (\d+)", text).group(1))
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-f]{8})u", text)]
+    assert levels == gen.LEVELS and len(words) == levels * 624
+    rs = np.random.RandomState(1234)
+    x = gen.mt_words(rs.get_state()[1].astype(np.uint32), 2 * gen.DEG + gen.N + 8)
+    C, L = gen.berlekamp_massey([x[k] >> 31 for k in range(1, 2 * gen.DEG + 1)])
+    assert L == gen.DEG
+    phi = sum(((C >> i) & 1) << (L - i) for i in range(L + 1))
+    g = gen.power_of_t(gen.J, phi)
+    for lvl in range(levels):
+        have = sum(w << (32 * i) for i, w in enumerate(words[lvl * 624:(lvl + 1) * 624]))
+        assert have == g, lvl
+        g = gen.gf2_mod(gen.gf2_square(gen.gf2_mod(gen.gf2_square(g), phi)), phi)
