@@ -664,6 +664,37 @@ __global__ __launch_bounds__(WMF_THREADS, 2) void wmf_seg_kernel(const int32_t *
     }
 }
 
+// Long rows, finished with the register solve: one workgroup of NW waves per row, lane j loads row j of
+// A = A0 + (w-1) G and b_j = w * sum_j straight from the scratch the segments accumulated (64 scattered row reads per
+// instruction, but only ~10^3 rows) and runs solve_reg.  The in-LDS Cholesky finish below took 0.5-0.7 ms per item sweep
+// (24-100 us per row, two workgroups per CU), a tenth of the K=64 epoch.
+template <int T32, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_long_reg_kernel(const int32_t *__restrict__ long_rows,
+                                                                              float *__restrict__ X, const float *__restrict__ A0,
+                                                                              const float *__restrict__ scratch, float weight) {
+    constexpr int K = 32 * T32;
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    extern __shared__ unsigned char smem_raw[];
+    float *colbuf = reinterpret_cast<float *>(smem_raw);   // [2][64 NW]
+    float *bbuf = colbuf + 2 * 64 * NW;                    // [2][64 NW]
+    int j = threadIdx.x;
+    asm volatile("" : "+v"(j));
+    const int jr = j < K ? j : 0;
+    const int32_t i = long_rows[blockIdx.x];
+    const float *G = scratch + (size_t)blockIdx.x * (K * K + K);
+    const f4 *a0 = reinterpret_cast<const f4 *>(A0 + (size_t)jr * K);
+    const f4 *g4 = reinterpret_cast<const f4 *>(G + (size_t)jr * K);
+    f32x2 a[K / 2];
+#pragma unroll
+    for (int g = 0; g < K / 4; ++g) {
+        const f4 v = a0[g] + (weight - 1.0f) * g4[g];
+        a[2 * g] = f32x2{v[0], v[1]};
+        a[2 * g + 1] = f32x2{v[2], v[3]};
+    }
+    const float x = solve_reg<K, NW>(a, weight * G[K * K + jr], j, colbuf, bbuf);
+    if (j < K) X[(int64_t)i * K + j] = x;
+}
+
 // long rows: A = A0 + (w-1) G, b = w * sum, both from the scratch the segments accumulated
 __global__ __launch_bounds__(WMF_THREADS) void wmf_long_finish_kernel(int K, const int32_t *__restrict__ long_rows,
                                                                      float *__restrict__ X, const float *__restrict__ A0,
@@ -838,7 +869,21 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             default: WMF_LAUNCH_(4); break;
             }
 #undef WMF_LAUNCH_
-            if (nlong > 0) {
+            if (nlong > 0 && h->reg_solve) {
+#define WMF_FINISH_(T32_)                                                                                                   \
+    do {                                                                                                                    \
+        constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                            \
+        hipLaunchKernelGGL((wmf_long_reg_kernel<T32_, NW_>), dim3(nlong), dim3(64 * NW_), sizeof(float) * 4 * 64 * NW_,      \
+                           h->stream, h->d_long_rows[side].p, Xf_all, Gf, h->d_scratch.p, (float)h->weight);                \
+    } while (0)
+                switch (K / 32) {
+                case 1: WMF_FINISH_(1); break;
+                case 2: WMF_FINISH_(2); break;
+                case 3: WMF_FINISH_(3); break;
+                default: WMF_FINISH_(4); break;
+                }
+#undef WMF_FINISH_
+            } else if (nlong > 0) {
                 CYMF_TRY(allow_lds(wmf_long_finish_kernel, smem));
                 hipLaunchKernelGGL(wmf_long_finish_kernel, dim3(nlong), dim3(WMF_THREADS), smem, h->stream, K, h->d_long_rows[side].p, Xf_all, Gf,
                                    h->d_scratch.p, (float)h->weight);
