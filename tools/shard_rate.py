@@ -1,9 +1,14 @@
 """Per-rank step rate of a 1/8 user shard of C3 without a communicator: what a rank of an 8-GPU job does minus the exchange."""
-import sys, time
+import os
+import sys
+import time
+
 import numpy as np
-sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
-from cymf_amd import dist, synthetic, _lib
-from cymf_amd.bpr import BprTrainer
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from cymf_amd import dist, synthetic  # noqa: E402
+from cymf_amd.bpr import BprTrainer  # noqa: E402
+
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 U, I, nnz, K, seed = synthetic.CONFIGS["C3"]
 rows, cols, indptr = synthetic.implicit_matrix_large(U, I, nnz, seed)
