@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
         // Every wave accumulates EVERY tile, over its share of the gathered rows (the k=2 MFMA steps are dealt to the waves in
         // turn): a gathered row is read from memory by one wave only -- with the tiles dealt out instead, both waves of a K=128
         // row read all of it, and the gather (L2 misses into a 14-70 MB table) is what bounds this phase.  The partial tiles meet
-        // in the LDS stage (stage_rounds).  Wave 0's accumulators start from the tile of A0 = YtY + lambda I, pre-divided by
+        // in the LDS stage (stage_rounds).  The accumulators start from the tile of A0 = YtY + lambda I (tile t on wave t % NW), pre-divided by
         // (w - 1): what is staged later, acc (w - 1), is then the finished A = A0 + (w - 1) G.
         f32x16 acc[NT];
         float bsum[T32];
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
             const float *a0l = A0 + a0off;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (wave == 0) {
+                if (wave == t % NW) {                            // each tile of A0 enters the sum once; the waves share the loads
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         acc[t][r] = a0l[(32 * tile_m(t) + (r & 3) + 8 * (r >> 2)) * K + 32 * tile_n(t)] * inv_w1;
