@@ -35,6 +35,21 @@ lines = [f"# rocprofv3 summary {tag}", "", "## --kernel-trace --stats (python3 b
 f = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
 for r in csv.DictReader(open(f)):
     lines.append(f'| {kname(r["Name"])} | {r["Calls"]} | {float(r["TotalDurationNs"])/1e6:.3f} | {float(r["AverageNs"])/1e3:.2f} | {float(r["Percentage"]):.2f} |')
+# the dominant kernel over the TIMED launches only (the stats row above includes the warm-up launches and the first-launch outlier),
+# next to what bench.py measured with HIP events in the same profiled run (<stats_dir>.log, if it is there)
+tr = glob.glob(os.path.join(stats_dir, "**", "*_kernel_trace.csv"), recursive=True)
+if tr:
+    rows = [r for r in csv.DictReader(open(tr[0])) if "bpr_step_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    timed = dur[5:] if len(dur) > 5 else dur
+    note = f"bpr_step_kernel over the {len(timed)} timed launches (warm-up of 5 excluded): rocprofv3 mean {sum(timed)/len(timed):.1f} us"
+    log = stats_dir.rstrip("/") + ".log"
+    if os.path.exists(log):
+        m = re.findall(r'"avg_launch_ms": ([0-9.]+)', open(log).read())
+        if m:
+            note += f"; bench.py's HIP events in the same run: {float(m[-1])*1e3:.1f} us"
+    lines += ["", note + "."]
 fetch, nf = counters(fetch_dir, "FETCH_SIZE")
 write, nw = counters(write_dir, "WRITE_SIZE")
 lines += ["", "## --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KiB per dispatch, mean)", "",
