@@ -89,10 +89,17 @@ class GloVe(object):
 def read_text(fname, min_count=5, window_size=10):
     """Co-occurrence builder (cymf/glove.pyx:183-241): one-sided window, weight 1/distance,
     words rarer than min_count dropped, vocabulary ids in order of first appearance.
-    Returns (csr_matrix (V,V) with X[cur, prev] accumulated, index->word dict)."""
+    Returns (csr_matrix (V,V) with X[cur, prev] accumulated, index->word dict).
+
+    Multi-line files, as the reference treats them (:199-203): the counts are taken on
+    `raw.replace("\n", "<eos>").split(" ")`, so the last word of a line and the first word of the next
+    are ONE token "last<eos>first" and neither occurrence counts for its word, while the
+    windows are built per line of `raw.split("\n")`.  `count` is a plain dict there: a word that only ever
+    stands at a line boundary (or the empty token of a trailing newline) is missing from it and the
+    lookup raises KeyError -- kept (a Counter would silently drop the word instead)."""
     with open(fname) as f:
         raw = f.read()
-    count = Counter(raw.replace("\n", "<eos>").split(" "))
+    count = dict(Counter(raw.replace("\n", "<eos>").split(" ")))
     w2i, i2w, lines_ids = {}, {}, []
     for line in raw.split("\n"):
         ids = []

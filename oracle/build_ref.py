@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Build the REFERENCE's own hot-path modules into oracle/_ref/ (test infrastructure only).
+"""Build the REFERENCE's own hot-path modules (test infrastructure only) OUTSIDE this repository.
 
-This compiles the reference's Cython sources *where they lie* under /root/reference
-(nothing is copied into this repository, nothing is written outside oracle/_ref/).
-It exists only in the build container: /root/reference does not travel to the GPU box,
-and the product (cymf_amd/) never imports anything from oracle/.
+This compiles the reference's Cython sources *where they lie* under /root/reference into
+`ref_dir()` = $CYMF_REF_BUILD_DIR or <tempdir>/cymf_amd_ref -- never under the repository root:
+gpurun ships the whole tree (git-ignored files included) to the GPU box, and the reference must not
+travel in any form, compiled or otherwise.  Nothing is copied into this repository.
+It works only in the build container (/root/reference does not exist on the GPU box); there the tests
+that compare against the compiled reference skip, and the committed fixtures (tests/golden/*.npz,
+generated from it by tests/golden/make_golden.py) keep the bit-exact pin.
+The product (cymf_amd/) never imports anything from oracle/.
 
 What is built (unchanged sources, the reference's own toolchain = Cython + g++):
     cymf/math.pyx, optimizer.pyx, model.pyx, bpr.pyx, relmf.pyx, glove.pyx, metrics.pyx
@@ -17,7 +21,7 @@ What is NOT built, and why (recorded in DESIGN.md):
     cymf/evaluator.pyx -- does not compile under Cython 3 (stray ')' at :89 and :137) and
         cannot be fixed without editing a copy of the source -> unbuildable.
     cymf/__init__.py is not used: it imports the dataset loaders which need `wget`.
-        oracle/_ref/cymf/__init__.py is an empty file of ours, so `import cymf.bpr` works.
+        <ref_dir>/cymf/__init__.py is an empty file of ours, so `import cymf.bpr` works.
 
 Usage:  python oracle/build_ref.py        (idempotent; skips if up to date)
 """
@@ -25,10 +29,19 @@ import os
 import subprocess
 import sys
 import sysconfig
+import tempfile
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "_ref")
+ROOT = os.path.dirname(HERE)
+
+
+def ref_dir() -> str:
+    """Where the compiled reference lives: outside the repository, so that it cannot ship with it."""
+    d = os.path.abspath(os.environ.get("CYMF_REF_BUILD_DIR") or os.path.join(tempfile.gettempdir(), "cymf_amd_ref"))
+    if os.path.commonpath([d, ROOT]) == ROOT:
+        raise RuntimeError(f"CYMF_REF_BUILD_DIR={d} is inside the repository; the compiled reference must stay outside")
+    return d
 MODULES = ["math", "optimizer", "model", "bpr", "relmf", "glove", "metrics"]
 
 
@@ -39,10 +52,11 @@ def available() -> bool:
 def build(verbose: bool = True) -> bool:
     if not available():
         if verbose:
-            print("[oracle/_ref] /root/reference absent: using prebuilt files if any")
+            print("[oracle ref] /root/reference absent: nothing to build (fixtures in tests/golden keep the pin)")
         return False
     import numpy
 
+    OUT = ref_dir()
     pkg = os.path.join(OUT, "cymf")
     bld = os.path.join(OUT, "build")
     os.makedirs(pkg, exist_ok=True)
@@ -60,7 +74,7 @@ def build(verbose: bool = True) -> bool:
         if os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(src):
             continue
         if verbose:
-            print(f"[oracle/_ref] cython {src}")
+            print(f"[oracle ref] cython {src}")
         subprocess.check_call(
             [sys.executable, "-m", "cython", "--cplus", "-3", "-X", "legacy_implicit_noexcept=True",
              src, "-o", cpp],
@@ -71,13 +85,17 @@ def build(verbose: bool = True) -> bool:
             cmd += ["-I", i]
         cmd += [cpp, "-o", so]
         if verbose:
-            print(f"[oracle/_ref] g++ -> {so}")
+            print(f"[oracle ref] g++ -> {so}")
         subprocess.check_call(cmd)
     return True
 
 
 def import_ref():
-    """Return the compiled reference package (cymf.bpr etc.), or None if not built."""
+    """Return the compiled reference modules (cymf.bpr etc.), or None where /root/reference is absent
+    or the build failed.  Never loads anything from under the repository root."""
+    if not available():
+        return None
+    OUT = ref_dir()
     pkg = os.path.join(OUT, "cymf")
     if not os.path.isdir(pkg):
         return None
@@ -87,7 +105,7 @@ def import_ref():
         import importlib
         mods = {m: importlib.import_module("cymf." + m) for m in ("bpr", "relmf", "glove", "math", "metrics")}
     except Exception as e:  # pragma: no cover
-        print("[oracle/_ref] import failed:", e)
+        print("[oracle ref] import failed:", e)
         return None
     return mods
 
@@ -96,4 +114,4 @@ if __name__ == "__main__":
     ok = build()
     if ok:
         mods = import_ref()
-        print("[oracle/_ref] built:", sorted(mods) if mods else None)
+        print("[oracle ref] built:", sorted(mods) if mods else None)

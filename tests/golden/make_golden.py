@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz from the REFERENCE itself (build container only).
 
-Needs oracle/_ref (python oracle/build_ref.py), i.e. /root/reference compiled in place with
-its own toolchain.  Fixtures are data only: seeded inputs + the reference's outputs.
+Needs the reference compiled by oracle/build_ref.py (built OUTSIDE the repository, in
+build_ref.ref_dir()), i.e. /root/reference compiled in place with its own toolchain.
+Fixtures are data only: seeded inputs + the reference's outputs.
 What cannot be generated from the reference here, and what stands in for it:
   * index stream: UniformGenerator is a cdef class -> libstdc++ <random> called directly
     (tests/golden/gen_stream.cpp), the very code the reference executes (cymf/math.pxd:31-39).
@@ -22,7 +23,11 @@ from scipy import sparse
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+from oracle import build_ref  # noqa: E402
+
+assert build_ref.build(verbose=False), "needs /root/reference (build container only)"
+REF_DIR = build_ref.ref_dir()
+sys.path.insert(0, REF_DIR)
 
 from cymf_amd.synthetic import implicit_matrix  # noqa: E402
 
@@ -39,7 +44,7 @@ def save(name, **kw):
 
 
 def stream_fixtures():
-    exe = os.path.join(ROOT, "oracle", "_ref", "gen_stream")
+    exe = os.path.join(REF_DIR, "gen_stream")
     subprocess.check_call(["g++", "-O2", "-std=c++11", os.path.join(HERE, "gen_stream.cpp"), "-o", exe])
     out = {}
     for rng_range in (1682, 3706, 100000, 7, 943 * 1682, 2**32 - 1, 2**32, 2**32 + 12345, 5 * 2**32 + 3):

@@ -147,6 +147,57 @@ def test_read_text_matches_reference_loop(tmp_path):
     assert [i2w[i] for i in range(V)] == list(w2i)
 
 
+def test_read_text_three_lines_counts_are_glued_at_line_ends(tmp_path):
+    """cymf/glove.pyx:199-203: counts come from raw.replace("\\n", "<eos>").split(" "), windows from raw.split("\\n").
+    Here 'c' occurs three times, but twice glued to a neighbour ("c<eos>b", "b<eos>c") -> count 1 -> dropped at
+    min_count=2, and 'b' counts 3 of its 5 occurrences.  A per-line count would keep 'c'."""
+    f = tmp_path / "three.txt"
+    f.write_text("a b a b c\nb a c a b\nc a b a")
+    M, i2w = read_text(str(f), min_count=2, window_size=2)
+    assert i2w == {0: "a", 1: "b"}
+    # kept ids per line: [0,1,0,1], [1,0,0,1], [0,1,0]; X[cur, prev] += 1/(j-k) for k in (j-2, j-1)
+    D = np.zeros((2, 2))
+    for ids in ([0, 1, 0, 1], [1, 0, 0, 1], [0, 1, 0]):
+        for j in range(len(ids)):
+            for k in range(max(0, j - 2), j):
+                D[ids[j], ids[k]] += 1.0 / (j - k)
+    # by hand: a<-a: .5 (l1) + 1 (l2) + .5 (l3); a<-b: 1 (l1) + 1+.5 (l2) + 1 (l3); b<-a: 1+1 (l1) + 1+.5 (l2) + 1 (l3); b<-b: .5 (l1)
+    assert np.array_equal(D, np.array([[2.0, 3.5], [4.5, 0.5]]))
+    assert M.shape == (2, 2) and np.array_equal(M.toarray(), D)
+    # with min_count=1 all three words are kept, in order of first appearance
+    M1, i2w1 = read_text(str(f), min_count=1, window_size=2)
+    assert i2w1 == {0: "a", 1: "b", 2: "c"} and M1.shape == (3, 3)
+    assert M1[2, 1] == 1.0 + 0.5 and M1[2, 0] == 0.5 + 1.0   # 'c' after "a b" (l1) and after "b a" (l2); line 3 starts with it
+
+
+def test_read_text_word_only_at_a_line_boundary_raises_keyerror_like_the_reference(tmp_path):
+    """`count` is a dict (cymf/glove.pyx:203): 'y' only exists inside the glued token "y<eos>z" -> count['y'] raises."""
+    f = tmp_path / "glued.txt"
+    f.write_text("x y\nz")
+    with pytest.raises(KeyError):
+        read_text(str(f), min_count=1, window_size=2)
+    g = tmp_path / "trailing_newline.txt"   # the empty last line's "" token is not in count either
+    g.write_text("x x x\n")
+    with pytest.raises(KeyError):
+        read_text(str(g), min_count=1, window_size=2)
+
+
+def test_save_word2vec_format_bytes(tmp_path):
+    """cymf/glove.pyx:164-177: header "V K", then "<word> <str(float64)> ..." per row, '\\n' line ends."""
+    from cymf_amd import GloVe
+    g = GloVe(num_components=4)
+    g.W = np.array([[0.5, -1.25, 3.0, 1e-05], [0.1, 2.0, -0.0, 1e16], [1.0 / 3.0, 7.0, 8.5, -2.5e-300]])
+    path = tmp_path / "vec.txt"
+    g.save_word2vec_format(str(path), {0: "the", 1: "of", 2: "<eos>"})
+    assert path.read_bytes() == (b"3 4\n"
+                                 b"the 0.5 -1.25 3.0 1e-05\n"
+                                 b"of 0.1 2.0 -0.0 1e+16\n"
+                                 b"<eos> 0.3333333333333333 7.0 8.5 -2.5e-300\n")
+    # a list works as the index->word map too (the reference only indexes it)
+    g.save_word2vec_format(str(path), ["a", "b", "c"])
+    assert path.read_text().splitlines()[1].split(" ")[0] == "a"
+
+
 def test_synthetic_configs_have_the_stated_shape():
     X, K = synthetic.config_matrix("C1")
     assert X.shape == (943, 1682) and X.nnz == 44853 and K == 20
