@@ -1,7 +1,9 @@
 """ctypes binding of libcymf_hip.so (include/cymf_amd.h).  No CPU fallback: if the HIP
 library is missing or no gfx950 device is visible the compute calls raise."""
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -13,6 +15,45 @@ OPT_IDS = {"sgd": 0, "adagrad": 1, "adam": 2}
 DTYPE_IDS = {"float32": 0, "f32": 0, "float64": 1, "f64": 1}
 MODE_IDS = {"exact": 0, "throughput": 1}
 UNIQUE_ID_BYTES = 128
+
+
+# Live native handles.  Python does not promise to run __del__ for objects that are still alive at interpreter
+# shutdown, and when it does run them the order is arbitrary -- a trainer freed late called hipStreamDestroy / hipFree
+# while the process was already inside exit() (round 1: SIGSEGV after rocprofv3's tool finalization).  So every wrapper
+# registers itself here and an atexit hook closes what is still open BEFORE interpreter teardown, trainers and
+# evaluators first, communicators (which they reference) last.
+_live = [weakref.WeakSet(), weakref.WeakSet()]
+
+
+def track(obj, last=False):
+    _live[1 if last else 0].add(obj)
+    return obj
+
+
+def close_all():
+    """Close every live trainer / evaluator / communicator handle (also the atexit hook)."""
+    for group in _live:
+        for o in list(group):
+            try:
+                o.close()
+            except Exception:
+                pass
+    if _lib is not None:
+        try:
+            if _lib.cymf_device_count() > 0:
+                _lib.cymf_device_sync(0)   # nothing in flight when the runtime's own exit handlers run
+        except Exception:
+            pass
+
+
+atexit.register(close_all)
+
+
+def out_f64(*arrays):
+    """Download targets are written through raw pointers: they must be C-contiguous float64 ndarrays."""
+    for a in arrays:
+        if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous or not a.flags.writeable:
+            raise ValueError("download targets must be writeable C-contiguous float64 ndarrays")
 
 
 class CymfError(RuntimeError):
@@ -38,6 +79,7 @@ def lib():
         "cymf_device_name": ([ci, C.c_char_p, ci], ci),
         "cymf_device_sync": ([ci], ci),
         "cymf_device_stream_copy_gbps": ([ci, i64, ci, vp], ci),
+        "cymf_device_seam_probe": ([ci, ci, ci, vp, vp], ci),
         "cymf_rng_fill_uniform": ([ci, u32, u64, i64, i64, vp], ci),
         "cymf_bpr_create": ([pp, i32, i32, i32, ci, f64, f64, u32, ci, ci, ci], ci),
         "cymf_bpr_set_data": ([vp, vp, vp, i64, vp, vp, vp, i64], ci),
@@ -148,6 +190,16 @@ def stream_copy_gbps(device=0, nbytes=1 << 30, iters=10):
     out = C.c_double(0.0)
     check(lib().cymf_device_stream_copy_gbps(device, int(nbytes), int(iters), C.byref(out)))
     return out.value
+
+
+def seam_probe(device=0, memtype=0, rounds=64):
+    """cymf_device_seam_probe: stale words seen at the four producer->consumer seams (all 0 on a healthy stack)."""
+    stale = np.zeros(4, dtype=np.int64)
+    words = C.c_int64(0)
+    check(lib().cymf_device_seam_probe(device, int(memtype), int(rounds), ptr(stale), C.byref(words)))
+    names = ("next_kernel_all_cus", "next_kernel_one_workgroup", "other_stream_behind_event", "copy_engine_to_host")
+    return {"memtype": ("hipMalloc", "fine-grained", "uncached")[int(memtype)], "words_per_seam": int(words.value),
+            **{n: int(v) for n, v in zip(names, stale)}}
 
 
 def rng_fill_uniform(seed, rng_range, n, skip=0, device=0):

@@ -100,6 +100,7 @@ class BprTrainer:
         self.h = C.c_void_p()
         _lib.check(self.L.cymf_bpr_create(C.byref(self.h), self.U, self.I, self.K, _lib.OPT_IDS[optimizer], lr, wd,
                                           neg_seed, _lib.DTYPE_IDS[dtype], _lib.MODE_IDS[mode], device))
+        _lib.track(self)
         self.N = 0
         if mode == "throughput" and steps_per_epoch != 1:
             _lib.check(self.L.cymf_bpr_set_steps_per_epoch(self.h, int(steps_per_epoch)))
@@ -129,8 +130,7 @@ class BprTrainer:
 
     def download(self, W, H):
         """Writes into the given C-contiguous float64 arrays (in place, as the reference trains)."""
-        if not (W.flags.c_contiguous and H.flags.c_contiguous and W.dtype == np.float64 and H.dtype == np.float64):
-            raise ValueError("download targets must be C-contiguous float64")
+        _lib.out_f64(W, H)
         _lib.check(self.L.cymf_bpr_download(self.h, _lib.ptr(W), _lib.ptr(H)))
 
     def epochs(self, n=1):

@@ -561,6 +561,7 @@ int upload_f64(DevBuf<T> &dst, const double *src, size_t n, hipStream_t s) {
     CYMF_TRY(dst.alloc(n));
     if constexpr (sizeof(T) == sizeof(double)) {
         CYMF_HIP(hipMemcpyAsync(dst.p, src, n * sizeof(double), hipMemcpyHostToDevice, s));
+        CYMF_HIP(hipStreamSynchronize(s));   // the caller's array (possibly a temporary of the wrapper) is consumed on return
     } else {
         DevBuf<double> tmp;
         tmp.fine = staging_memtype();
@@ -915,6 +916,7 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
         h->h_last_neg.assign((size_t)N, -1);
         std::vector<int32_t> tu, ti, tj;
         std::vector<uint32_t> ku, ki, kj;
+        struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } keep_sources_alive{h->stream};   // also on error returns
         tu.reserve((size_t)N); ti.reserve((size_t)N); tj.reserve((size_t)N);
         ku.reserve((size_t)N); ki.reserve((size_t)N); kj.reserve((size_t)N);
         for (int64_t l = 0; l < N; ++l) {
@@ -929,12 +931,12 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
         }
         const int64_t n_perf = (int64_t)tu.size(), n_skipped = N - n_perf;
         const double t_turns = now();
-        CYMF_TRY(h->d_tu.upload_into(tu.data(), tu.size(), (size_t)N, h->stream));
-        CYMF_TRY(h->d_ti.upload_into(ti.data(), ti.size(), (size_t)N, h->stream));
-        CYMF_TRY(h->d_tj.upload_into(tj.data(), tj.size(), (size_t)N, h->stream));
-        CYMF_TRY(h->d_ku.upload_into(ku.data(), ku.size(), (size_t)N, h->stream));
-        CYMF_TRY(h->d_ki.upload_into(ki.data(), ki.size(), (size_t)N, h->stream));
-        CYMF_TRY(h->d_kj.upload_into(kj.data(), kj.size(), (size_t)N, h->stream));
+        CYMF_TRY(h->d_tu.upload_into_async(tu.data(), tu.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
+        CYMF_TRY(h->d_ti.upload_into_async(ti.data(), ti.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
+        CYMF_TRY(h->d_tj.upload_into_async(tj.data(), tj.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
+        CYMF_TRY(h->d_ku.upload_into_async(ku.data(), ku.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
+        CYMF_TRY(h->d_ki.upload_into_async(ki.data(), ki.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
+        CYMF_TRY(h->d_kj.upload_into_async(kj.data(), kj.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
         CYMF_TRY(h->d_done.alloc((size_t)h->U + (size_t)h->I));
         CYMF_TRY(h->d_done.zero(h->stream));
         CYMF_TRY(h->d_err.alloc(1));
@@ -1622,7 +1624,7 @@ extern "C" int cymf_bpr_set_user_bounds(cymf_bpr *h, const int64_t *bounds) {
 
 extern "C" int cymf_bpr_destroy(cymf_bpr *h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    if (!cymf::runtime_alive(h->device)) return 0;   // process exit / runtime already torn down: leak quietly
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->rng_stream) (void)hipStreamSynchronize(h->rng_stream);
     for (auto &pe : h->prof_events) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }

@@ -213,7 +213,7 @@ extern "C" int cymf_comm_create_local_group(cymf_comm **out, int world, int devi
 
 extern "C" int cymf_comm_destroy(cymf_comm *c) {
     if (!c) return 0;
-    (void)hipSetDevice(c->device);
+    if (!cymf::runtime_alive(c->device)) return 0;   // process exit / runtime already torn down: leak quietly
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->grp && --c->grp->refs == 0) {   // (handles of a local group are destroyed from one thread, after the ranks have joined)
         (void)hipDeviceSynchronize();

@@ -34,6 +34,12 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 int use_device(int device);   // validates + hipSetDevice; CYMF_ERR_NO_DEVICE if none
+// false once the process is inside exit() (our atexit hook has run: the HIP runtime's own teardown follows it) or when
+// hipSetDevice no longer succeeds (hipErrorDeinitialized and friends).  The destroy entry points and DevBuf::release
+// then return without touching HIP: handles that outlive the runtime are leaked quietly instead of crashing in exit()
+// (gpurun_out/exact.log of round 1: SIGSEGV under exit() after rocprofv3's tool finalization, a trainer freed late).
+bool runtime_alive(int device);
+bool process_exiting();
 int staging_memtype();        // CYMF_STAGING_MEMTYPE, default 2 (uncached): buffers a kernel fills and a copy engine reads, or vice versa
 int default_memtype();        // CYMF_DEFAULT_MEMTYPE (0 coarse, 1 fine-grained, 2 uncached = default), read once
 
@@ -47,7 +53,7 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !process_exiting()) (void)hipFree(p);
         p = nullptr;
         n = 0;
     }
@@ -78,14 +84,28 @@ struct DevBuf {
     }
     // keep the allocation while it is large enough (per-epoch payloads whose size varies a little)
     int reserve(size_t count) { return (p && n >= count) ? 0 : alloc(count); }
-    int upload_into(const T *src, size_t count, size_t capacity, hipStream_t s = nullptr) {
+    // H2D copies.  upload()/upload_into() return only when the source has been consumed (copy + stream sync):
+    // callers hand in temporaries (std::vector staging in set_data) that die at the end of their block, and whether
+    // hipMemcpyAsync has finished reading a PAGEABLE source when it returns is not something HIP promises.
+    // The *_async forms skip the sync: the caller keeps `src` alive until it has synchronised `s` itself.
+    int upload_into_async(const T *src, size_t count, size_t capacity, hipStream_t s) {
         CYMF_TRY(reserve(capacity > count ? capacity : count));
         if (count) CYMF_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
         return 0;
     }
-    int upload(const T *src, size_t count, hipStream_t s = nullptr) {
+    int upload_async(const T *src, size_t count, hipStream_t s) {
         CYMF_TRY(alloc(count));
         if (count) CYMF_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+        return 0;
+    }
+    int upload_into(const T *src, size_t count, size_t capacity, hipStream_t s = nullptr) {
+        CYMF_TRY(upload_into_async(src, count, capacity, s));
+        if (count) CYMF_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+    int upload(const T *src, size_t count, hipStream_t s = nullptr) {
+        CYMF_TRY(upload_async(src, count, s));
+        if (count) CYMF_HIP(hipStreamSynchronize(s));
         return 0;
     }
     int zero(hipStream_t s = nullptr) {

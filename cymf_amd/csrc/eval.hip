@@ -341,7 +341,7 @@ extern "C" int cymf_eval_run(cymf_eval *h, const double *W, const double *H, int
 
 extern "C" int cymf_eval_destroy(cymf_eval *h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    if (!cymf::runtime_alive(h->device)) return 0;   // process exit / runtime already torn down: leak quietly
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
     return 0;

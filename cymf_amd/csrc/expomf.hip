@@ -238,7 +238,7 @@ extern "C" int cymf_expomf_epochs(cymf_expomf *h, int32_t n_epochs) {
 
 extern "C" int cymf_expomf_destroy(cymf_expomf *h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    if (!cymf::runtime_alive(h->device)) return 0;   // process exit / runtime already torn down: leak quietly
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
     return 0;

@@ -1076,7 +1076,7 @@ extern "C" int cymf_relmf_epochs(cymf_relmf *h, int32_t n_epochs, double *loss_o
 
 extern "C" int cymf_relmf_destroy(cymf_relmf *h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    if (!cymf::runtime_alive(h->device)) return 0;   // process exit / runtime already torn down: leak quietly
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
@@ -1397,7 +1397,7 @@ extern "C" int cymf_glove_epochs(cymf_glove *h, int32_t n_epochs, double *loss_o
 
 extern "C" int cymf_glove_destroy(cymf_glove *h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    if (!cymf::runtime_alive(h->device)) return 0;   // process exit / runtime already torn down: leak quietly
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
     return 0;

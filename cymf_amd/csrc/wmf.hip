@@ -1064,7 +1064,7 @@ extern "C" int cymf_wmf_epochs(cymf_wmf *h, int32_t n_epochs) {
 
 extern "C" int cymf_wmf_destroy(cymf_wmf *h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    if (!cymf::runtime_alive(h->device)) return 0;   // process exit / runtime already torn down: leak quietly
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
     delete h;
     return 0;

@@ -79,6 +79,7 @@ class Comm:
         self.h = C.c_void_p()
         buf = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
         _lib.check(self.L.cymf_comm_create(C.byref(self.h), buf, rank, world, device))
+        _lib.track(self, last=True)
 
     @classmethod
     def local_group(cls, world, max_floats, device=0):
@@ -91,6 +92,7 @@ class Comm:
         for r in range(world):
             c = cls.__new__(cls)
             c.L, c.rank, c.world, c.device, c.h = L, r, world, device, C.c_void_p(arr[r])
+            _lib.track(c, last=True)
             out.append(c)
         return out
 

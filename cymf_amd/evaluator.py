@@ -46,6 +46,7 @@ class Evaluator(object):
                                           _lib.ptr(_lib.i32c(allp.indptr)), _lib.ptr(_lib.i32c(allp.indices)),
                                           _lib.ptr(prop), prop.size, self.device))
             self._h = h
+            _lib.track(self)
         return self._h
 
     def negatives(self, seed=1234):

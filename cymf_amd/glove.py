@@ -135,6 +135,7 @@ class GloveTrainer:
         self.h = C.c_void_p()
         _lib.check(self.L.cymf_glove_create(C.byref(self.h), self.V, self.Vc, self.K, lr, x_max, alpha,
                                             _lib.DTYPE_IDS[dtype], _lib.MODE_IDS[mode], device))
+        _lib.track(self)
         self.comm = comm
         if steps_per_epoch != 1:
             _lib.check(self.L.cymf_glove_set_steps_per_epoch(self.h, int(steps_per_epoch)))
@@ -157,6 +158,7 @@ class GloveTrainer:
         _lib.check(self.L.cymf_glove_upload(self.h, _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), _lib.ptr(d)))
 
     def download(self, W, bias, Wc, bias_c):
+        _lib.out_f64(W, bias, Wc, bias_c)
         _lib.check(self.L.cymf_glove_download(self.h, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(Wc), _lib.ptr(bias_c)))
 
     def epochs(self, n=1):

@@ -85,6 +85,7 @@ class RelMfTrainer:
         self.h = C.c_void_p()
         _lib.check(self.L.cymf_relmf_create(C.byref(self.h), self.U, self.I, self.K, _lib.OPT_IDS[optimizer], lr, wd,
                                             clip, seed, _lib.DTYPE_IDS[dtype], _lib.MODE_IDS[mode], device))
+        _lib.track(self)
         self.comm = comm
         if comm is not None:
             b = np.ascontiguousarray(user_bounds, dtype=np.int64)
@@ -104,6 +105,7 @@ class RelMfTrainer:
         _lib.check(self.L.cymf_relmf_upload(self.h, _lib.ptr(W), _lib.ptr(H)))
 
     def download(self, W, H):
+        _lib.out_f64(W, H)
         _lib.check(self.L.cymf_relmf_download(self.h, _lib.ptr(W), _lib.ptr(H)))
 
     def epochs(self, n=1):

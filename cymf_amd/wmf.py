@@ -70,6 +70,7 @@ class WmfTrainer:
         self.h = C.c_void_p()
         _lib.check(self.L.cymf_wmf_create(C.byref(self.h), self.U, self.I, self.K, weight, weight_decay,
                                           _lib.DTYPE_IDS[dtype], device))
+        _lib.track(self)
         self.comm = comm          # keeps the communicator alive as long as the trainer
         if comm is not None:
             _lib.check(self.L.cymf_wmf_attach_comm(self.h, comm.h))
@@ -87,6 +88,7 @@ class WmfTrainer:
         _lib.check(self.L.cymf_wmf_upload(self.h, _lib.ptr(W), _lib.ptr(H)))
 
     def download(self, W, H):
+        _lib.out_f64(W, H)
         _lib.check(self.L.cymf_wmf_download(self.h, _lib.ptr(W), _lib.ptr(H)))
 
     def row_range(self, side):

@@ -58,6 +58,14 @@ int cymf_device_sync(int device);
 /* measured HBM rate of a float4 device-to-device stream copy (read + write bytes per second, in GB/s):
  * the achievable-bandwidth yardstick printed beside the 8 TB/s datasheet peak */
 int cymf_device_stream_copy_gbps(int device, int64_t bytes, int iters, double *gbps_out);
+/* Diagnostic (no reference counterpart): does this box keep plain device memory coherent across the seams the
+ * trainers rely on?  `rounds` times, in a buffer of memory type `memtype` (0 hipMalloc, 1 fine-grained, 2 uncached):
+ *   every CU reads the buffer (all eight XCD L2s hold the old value) -> ONE workgroup rewrites it ->
+ *   [0] every CU re-reads it in the next kernel of the same stream, [1] one workgroup re-reads it,
+ *   [2] every CU re-reads it on a second stream behind an event, [3] the copy engine brings it to the host.
+ * stale_out[4] receives the number of words that still showed the old value at each seam, *words_out the words
+ * checked per seam.  All zero on a healthy stack; DESIGN.md section 2 records what the GPU boxes answered. */
+int cymf_device_seam_probe(int device, int memtype, int rounds, int64_t *stale_out, int64_t *words_out);
 
 /* ---------------------------------------------------------------- negative-sample index stream
  * UniformGenerator(a=0, b=range, seed): cymf/math.pyx:12-18, cymf/math.pxd:31-39

@@ -237,3 +237,88 @@ def test_invalid_inputs_fail_loudly():
         t.set_data([0], [1], [0, 1, 1, 1, 1], [1])
         t.epochs(1)
     t.close()
+
+
+def _first_order_prediction(W0, H0, users, pos, neg, lr):
+    """With weight_decay = 0 and a small lr every triplet's update is, to first order in lr, the gradient at the
+    INITIAL factors (the rows move by O(lr) and s = sigmoid(-x) by O(lr) with them): the sum over the triplets does
+    not depend on the order or interleaving in which wavefronts apply them -- but it does depend on every slot being
+    applied exactly once."""
+    dW, dH = np.zeros_like(W0), np.zeros_like(H0)
+    for u, i, j in zip(users, pos, neg):
+        if j < 0:
+            continue
+        x = W0[u] @ (H0[i] - H0[j])
+        s = 1.0 / (1.0 + np.exp(x))
+        dW[u] += lr * s * (H0[i] - H0[j])
+        dH[i] += lr * s * W0[u]
+        dH[j] -= lr * s * W0[u]
+    return dW, dH
+
+
+@pytest.mark.parametrize("item_aligned", [False, True])
+@pytest.mark.parametrize("opt", ["sgd", "adagrad", "adam"])
+@pytest.mark.parametrize("K", [8, 128])
+def test_step_kernel_boundaries_every_slot_exactly_once(K, opt, item_aligned, monkeypatch):
+    """The step kernel's boundary arithmetic, deterministically (round 1 recorded an abort inside cymf_bpr_epochs in
+    throughput mode whose cause could not be recovered -- DESIGN.md section 2b): a step of 64*4+1 slots walked by FIVE
+    wavefronts of one chunk each -- a partial last chunk of ONE slot, one positive item whose run of 200 slots spans
+    wavefronts 0..3 (wavefronts 1 and 2 lie entirely inside it: shared_first == shared_last), the ring refill reaching
+    over the chunk end into metadata past the step -- for all three optimizers, the strided (K=8) and the packed
+    (K=128) row layout, shared runs and item-aligned ranges (CYMF_BPR_ITEM_ALIGNED).  Every user owns ONE triplet, so
+    the result is order-independent to first order and is checked against the closed form."""
+    U, I, N = 257, 4000, 257   # few draws per item: a cold negative row is rarely in two wavefronts' hands at once
+    items = np.where(np.arange(U) < 200, 7, 8 + (np.arange(U) % 20)).astype(np.int32)
+    X = sparse.csr_matrix((np.ones(U), (np.arange(U), items)), shape=(U, I))
+    users, pos, indptr, indices = _trainer_inputs(X)
+    W0, H0 = oracle.reference_init(U, I, K)
+    W0, H0 = W0.astype(np.float32).astype(np.float64), H0.astype(np.float32).astype(np.float64)   # what the device holds
+    lr = 1e-5
+    monkeypatch.setenv("CYMF_BPR_MAX_WAVES", "5")
+    monkeypatch.setenv("CYMF_BPR_ROWS_PER_INFLIGHT", "1")
+    monkeypatch.setenv("CYMF_BPR_ADAPTIVE_RPI", "1")
+    monkeypatch.setenv("CYMF_BPR_ITEM_ALIGNED", "1" if item_aligned else "0")
+    monkeypatch.setenv("CYMF_BPR_HOT_THRESHOLD", "100")   # item 7 is hot: drawn as a negative it gets an atomic delta
+    t = BprTrainer(U, I, K, opt, lr, 0.0, mode="throughput")
+    t.set_data(users, pos, indptr, indices)
+    t.upload(W0, H0)
+    t.epochs(1)
+    neg = t.last_negatives()
+    W, H = np.empty_like(W0), np.empty_like(H0)
+    t.download(W, H)
+    performed, skipped = t.stats()
+    t.close()
+    assert np.array_equal(neg, np.where(items[users] == oracle.uniform_stream(1234, I, N), -1, oracle.uniform_stream(1234, I, N)))
+    assert performed == int((neg >= 0).sum()) and performed + skipped == N
+    dW, dH = _first_order_prediction(W0, H0, users, pos, neg, lr)
+    ok = neg >= 0
+    touchW = np.bincount(users[ok], minlength=U)
+    negH = np.bincount(neg[ok], minlength=I)
+    touchH = np.bincount(pos[ok], minlength=I) + negH
+    # HOGWILD by design may lose an update of a COLD negative row that two wavefronts hold at once (plain stores,
+    # cymf/bpr.pyx:162's regime); every other update is lossless: user rows (one triplet each), positive-side runs
+    # (register-resident, atomic deltas), the hot item as a negative (atomic delta), rows with a single touch
+    lossless = (negH == 0) | (touchH == 1)
+    lossless[7] = True
+    if opt == "adam":
+        # first touch of a row: m = 0.1 g, v = 0.001 g^2 -> step = lr g / (|g| + 1e-8) = lr sign(g) unless |g| ~ 1e-8.
+        # Exact for the user rows (one triplet each); item rows are touched repeatedly and only bounded here.
+        step = (W - W0)[touchW == 1]
+        assert (np.abs(step) <= lr * 1.02).all() and (np.abs(np.abs(step) - lr) <= 0.02 * lr).mean() > 0.99
+        assert (np.sign(step) == np.sign(dW[touchW == 1])).mean() > 0.99
+        assert np.array_equal((W - W0)[touchW == 0], np.zeros_like(W0[touchW == 0]))
+        assert (np.abs(H - H0) <= touchH[:, None] * lr * 1.02).all() and np.abs(H - H0)[7].min() > 0
+        assert np.array_equal((H - H0)[touchH == 0], np.zeros_like(H0[touchH == 0]))
+        return
+    # Per row, relative to the row's largest predicted change: 0.1 % second-order (the hot row moves by 200 * lr / 2 of itself),
+    # float32 rounding of an update against its row value <= 0.6 % per touch and random, AdaGrad's 1/sqrt(acc) < 0.01 %.
+    # The hot row (200 touches) is therefore pinned to 0.31 %: ONE missing or doubled update of it is 0.5 %.
+    for got, pred, touches, strict in ((W - W0, dW, touchW, np.ones(U, dtype=bool)), (H - H0, dH, touchH, lossless)):
+        ref = np.abs(pred).max(axis=1)
+        err = np.abs(got - pred).max(axis=1)
+        tol = 0.002 + 0.015 / np.sqrt(np.maximum(touches, 1))
+        bad = strict & (err > tol * ref + 1e-12)
+        assert not bad.any(), (np.flatnonzero(bad)[:5], (err / np.maximum(ref, 1e-30))[bad][:5], touches[bad][:5])
+        assert np.array_equal(got[touches == 0], np.zeros_like(got[touches == 0]))
+        assert (np.abs(got) <= touches[:, None] * lr * 0.5 * 0.2 / K * 1.05 + 1e-12).all()   # |s| <= ~1/2, |row entries| <= 0.1/K (x2 for a difference)
+    assert touchH[7] >= 190 and lossless.sum() > I - 40

@@ -141,3 +141,4 @@ if "eval" in what:
     t2 = time.perf_counter()
     print(f"Evaluator C4-shaped ({U} users, {Xte.nnz} held-out items, 100 negatives, K={K}): first call {1e3*(t1-t0):.0f} ms "
           f"(sequential candidate walk included), then {1e3*(t2-t1)/3:.1f} ms per call; {r}", flush=True)
+    ev.close()
