@@ -7,15 +7,23 @@
 Workload (config C3): synthetic 1M users x 100k items, 100M interactions
 (lognormal user activity, Zipf(1) item popularity, seed 102), K=128, SGD lr=0.05 wd=0.01, fp32,
 HOGWILD (throughput) mode.  A "step" = one window of the shuffled triplet order:
-~4M triplets per GPU (draw negative from the mt19937 stream, skip if positive, forward, backward).
+~4-5M triplets per GPU (draw negative from the mt19937 stream, skip if positive, forward, backward).
+The number of steps per epoch is the divisor of --steps nearest to nnz / (batch * N), so the timed
+window is a whole number of epochs (`epochs_covered`) and holds exactly that many epochs' worth of
+the per-epoch side-stream work (index-stream generation, skip tests): both streams are drained
+before the clock starts and before it stops.
 Users are sharded over the N ranks by nnz; with N > 1 every step ends with the RCCL all-reduce of
 the item-factor deltas.  Inputs are resident in HBM before the timed region.
 
 One JSON line on rank 0: value = performed triplet updates of all ranks / wall time of the K steps
 (barrier + device sync on both sides, max over ranks).  `roofline` prices the dominant kernel
 (bpr_step_kernel) with HIP events on its own stream: algorithmic bytes = 24K+12 per performed
-triplet against the 8 TB/s HBM3E peak.  `cpu_baseline` = the oracle (a fp64
+triplet against the 8 TB/s HBM3E peak; beside it the bytes the kernel cannot avoid
+(the positive item's row stays in registers across its run: 16K+12) and the PMC-measured bytes of
+profiles/traffic.json (static file, `traffic_source`).  `cpu_baseline` = the oracle (a fp64
 single-thread port of the reference's loop) on a bounded prefix of the same triplets, rank 0, N=1.
+`secondary` (N=1 only): BASELINE.json's other configs -- C2 BPR K=64, C4 WMF K=64, C5 GloVe K=100 --
+and RelMF 20000 x 8000 K=64, each with its own roofline object (SURVEY.md 8d figures).
 """
 import argparse
 import json
@@ -51,16 +59,56 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def nearest_divisor(k, ideal):
+    """The divisor of k closest (in ratio) to ideal: steps per epoch such that k steps are whole epochs."""
+    divs = [d for d in range(1, k + 1) if k % d == 0]
+    return min(divs, key=lambda d: abs(np.log(d / max(ideal, 1e-9))))
+
+
+def shared_dataset(rank, local, world, config, scale):
+    """The synthetic matrix and the fit's shuffled order, generated ONCE per node: local rank 0 writes them to
+    /dev/shm, the other ranks map them read-only (8 x 10 s of generation and 8 x the host memory otherwise)."""
+    U, I, nnz, K, seed = synthetic.CONFIGS[config]
+    if scale != 1.0:
+        U, nnz = max(int(U * scale), 1000), max(int(nnz * scale), 10000)
+
+    def generate():
+        rows, cols, indptr = synthetic.implicit_matrix_large(U, I, nnz, seed)
+        # the single shuffled order of the fit (cymf/bpr.pyx:104): same permutation on every rank
+        perm = np.random.default_rng(4321).permutation(len(rows))
+        return {"users": rows[perm], "positives": cols[perm], "cols": cols, "indptr": indptr.astype(np.int64)}
+
+    if world == 1:
+        return U, I, K, generate()
+    tag = f"cymf_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{config}_{scale}"
+    d = os.path.join("/dev/shm", tag)
+    names = ("users", "positives", "cols", "indptr")
+    if local == 0:
+        data = generate()
+        os.makedirs(d, exist_ok=True)
+        for n in names:
+            np.save(os.path.join(d, n + ".npy"), data[n])
+        open(os.path.join(d, "done"), "w").close()
+        return U, I, K, data
+    t0 = time.time()
+    while not os.path.exists(os.path.join(d, "done")):
+        if time.time() - t0 > 900:
+            raise TimeoutError("bench: the node's dataset never appeared in /dev/shm")
+        time.sleep(0.2)
+    return U, I, K, {n: np.load(os.path.join(d, n + ".npy"), mmap_mode="r") for n in names}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--batch", type=int, default=4_000_000, help="triplets per GPU per step")
+    ap.add_argument("--batch", type=int, default=5_000_000, help="target triplets per GPU per step")
     ap.add_argument("--optimizer", default="sgd")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="triplets timed on the CPU oracle (0 = skip)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs (C2 / C4 / C5 / RelMF)")
     args = ap.parse_args()
 
     rank, world, local = dist.env_rank_world()
@@ -68,27 +116,32 @@ def main():
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = local if os.environ.get("CYMF_BENCH_SAME_DEVICE") != "1" else 0   # (test hook: all ranks on device 0)
-    U, I, nnz, K, seed = synthetic.CONFIGS[args.config]
-    if args.scale != 1.0:
-        U, nnz = max(int(U * args.scale), 1000), max(int(nnz * args.scale), 10000)
     lr, wd = 0.05, 0.01
 
     t0 = time.time()
-    rows, cols, indptr = synthetic.implicit_matrix_large(U, I, nnz, seed)
-    nnz = len(rows)
-    log(rank, f"synthetic {args.config}: U={U} I={I} nnz={nnz} K={K} generated in {time.time()-t0:.1f}s")
-    # the single shuffled order of the fit (cymf/bpr.pyx:104): same permutation on every rank
-    perm = np.random.default_rng(4321).permutation(nnz)
+    U, I, K, data = shared_dataset(rank, local, world, args.config, args.scale)
+    indptr, cols = data["indptr"], data["cols"]
+    nnz = len(cols)
+    log(rank, f"synthetic {args.config}: U={U} I={I} nnz={nnz} K={K} ready in {time.time()-t0:.1f}s")
     comm = None
     if world > 1:
         comm = dist.Comm.from_env(device=device)
         lo, hi = dist.user_shards(indptr, world)[rank]
-        mine = np.nonzero((rows[perm] >= lo) & (rows[perm] < hi))[0]     # global positions of my triplets
-        users, positives, gpos = rows[perm[mine]], cols[perm[mine]], mine.astype(np.int64)
+        all_users = data["users"]
+        mine = np.nonzero((all_users >= lo) & (all_users < hi))[0]       # global positions of my triplets
+        users, positives, gpos = np.asarray(all_users[mine]), np.asarray(data["positives"][mine]), mine.astype(np.int64)
+        # the membership structure (cymf/bpr.pyx:146-147) of this rank's users only: other users' rows are empty
+        ip = np.zeros(U + 1, dtype=np.int64)
+        ip[lo:hi + 1] = indptr[lo:hi + 1] - indptr[lo]
+        ip[hi + 1:] = ip[hi]
+        csr_indptr, csr_indices = ip.astype(np.int32), np.ascontiguousarray(cols[indptr[lo]:indptr[hi]])
     else:
-        users, positives, gpos = rows[perm], cols[perm], None
-    spe = max(1, int(round(nnz / (args.batch * world))))
-    log(rank, f"rank {rank}/{world}: {len(users)} local triplets, {spe} steps/epoch (~{nnz // (spe * world)} triplets/GPU/step)")
+        users, positives, gpos = data["users"], data["positives"], None
+        csr_indptr, csr_indices = indptr.astype(np.int32), cols
+    spe = nearest_divisor(args.steps, nnz / (args.batch * world))
+    epochs_covered = args.steps // spe
+    log(rank, f"rank {rank}/{world}: {len(users)} local triplets, {spe} steps/epoch (~{nnz // (spe * world)} triplets/GPU/step), "
+              f"timed window = {epochs_covered} epoch(s)")
 
     rs = np.random.RandomState(4321)   # the reference's init (cymf/bpr.pyx:97-101), identical on every rank
     W0 = rs.uniform(-0.1, 0.1, size=(U, K)) / K
@@ -97,12 +150,12 @@ def main():
     trainer = BprTrainer(U, I, K, args.optimizer, lr, wd, dtype="float32", mode="throughput", device=device,
                          steps_per_epoch=spe, comm=comm)
     t0 = time.time()
-    trainer.set_data(users, positives, indptr.astype(np.int32), cols, gpos, nnz)
+    trainer.set_data(users, positives, csr_indptr, csr_indices, gpos, nnz)
     trainer.upload(W0, H0)
     log(rank, f"device setup {time.time()-t0:.1f}s on {_lib.device_name(device)}")
 
     def barrier():
-        trainer.sync()
+        trainer.sync()               # drains the step stream AND the side stream (index stream, skip tests)
         if comm is not None:
             comm.barrier()
 
@@ -132,14 +185,22 @@ def main():
 
     value = performed / elapsed
     bytes_per_triplet = {"sgd": 24 * K + 12, "adagrad": 48 * K + 12, "adam": 72 * K + 12}[args.optimizer]
+    # what the kernel cannot avoid moving: H[i] stays in registers across the item run
+    min_bytes_per_triplet = {"sgd": 16 * K + 12, "adagrad": 32 * K + 12, "adam": 48 * K + 12}[args.optimizer]
     avg_launch_s = (k_ms / 1e3) / max(k_launches, 1)
-    achieved = bytes_per_triplet * (performed_local / max(k_launches, 1)) / max(avg_launch_s, 1e-12)
+    per_launch = performed_local / max(k_launches, 1)
+    achieved = bytes_per_triplet * per_launch / max(avg_launch_s, 1e-12)
+    achieved_min = min_bytes_per_triplet * per_launch / max(avg_launch_s, 1e-12)
 
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"bpr_step_{args.optimizer}_K{K}")
+            tj = json.load(open(tpath))
+            traffic = tj.get(f"bpr_step_{args.optimizer}_K{K}")
+            if traffic is not None:
+                traffic_source = ("profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of "
+                                  f"{tj.get('triplets_per_launch', '4.0 M')} slots, not measured in this run)")
         except Exception:
             traffic = None
 
@@ -181,6 +242,13 @@ def main():
         except Exception:
             copy_gbps = None
 
+    trainer.close()
+    del trainer
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        del data, users, positives, W0, H0
+        secondary = secondary_paths(device, args.scale)
+
     if rank == 0:
         out = {
             "metric": "BPR triplet-updates/sec at K=128",
@@ -192,24 +260,174 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
+            "scaling_note": "fixed data set (C3) sharded by user: the per-GPU step stays at ~4-6 M triplets, the global step grows "
+                            "with N and the steps per epoch shrink as 1/N (synchronous mini-batch on the item table, SURVEY.md 8e)",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "epochs_covered": epochs_covered,
             "config": {"workload": f"{args.config}: {U} users x {I} items, {nnz} interactions, K={K}, "
                                    f"{args.optimizer} lr={lr} wd={wd}, HOGWILD mode",
                        "triplets_per_gpu_per_step": nnz // (spe * world), "steps_per_epoch": spe,
                        "sharding": f"users x{world}" + (", RCCL all-reduce of item deltas per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "bpr_step_kernel", "avg_launch_ms": 1e3 * avg_launch_s, "launches": k_launches,
-                         "bytes_per_unit": bytes_per_triplet, "stream_copy_GBps": copy_gbps},
+                         "bytes_per_unit": bytes_per_triplet,
+                         "basis": "algorithmic bytes of SURVEY.md 8d (3 rows read + written + indices per performed triplet)",
+                         "achieved_min_traffic": achieved_min / 1e9, "frac_min_traffic": achieved_min / HBM_PEAK,
+                         "min_bytes_per_unit": min_bytes_per_triplet,
+                         "frac_measured_traffic": (traffic / max(avg_launch_s, 1e-12) / HBM_PEAK) if traffic else None,
+                         "stream_copy_GBps": copy_gbps},
             "cpu_baseline": cpu,
             "skipped_draws": int(s_after),
+            "secondary": secondary,
         }
         print(json.dumps(out), flush=True)
-    trainer.close()
     if comm is not None:
         comm.close()
+    if world > 1 and local == 0:   # the node's dataset in /dev/shm (every rank has mapped it by now: the barriers above)
+        import shutil
+        shutil.rmtree(os.path.join("/dev/shm", f"cymf_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{args.config}_{args.scale}"),
+                      ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------ secondary configs
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, MI355X_MICROARCH.md chip table (fp32 matrix = fp32 vector rate)
+
+
+def _timed_epochs(run, n, device):
+    """ms per call of run() (one epoch), device-synchronised wall time over n calls after one warm-up call."""
+    run()
+    _lib.device_sync(device)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    _lib.device_sync(device)
+    return 1e3 * (time.perf_counter() - t0) / n
+
+
+def _hbm_roofline(units, bytes_per_unit, ms, kernel):
+    a = units * bytes_per_unit / (ms * 1e-3)
+    return {"bound": "hbm", "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": a / HBM_PEAK,
+            "bytes_per_unit": bytes_per_unit, "kernel": kernel, "traffic": None,
+            "timing": "device-synchronised wall time per epoch (all kernels of the epoch, launch gaps included)"}
+
+
+def secondary_paths(device, scale=1.0):
+    """BASELINE.json configs 2, 4, 5 and RelMF on the same GPU, one object each: value, unit, ms per epoch and a
+    roofline priced with SURVEY.md 8d's algorithmic figures.  Failures are recorded, never raised: the headline stands."""
+    from scipy import sparse
+    from cymf_amd.glove import GloveTrainer
+    from cymf_amd.relmf import RelMfTrainer
+    from cymf_amd.wmf import WmfTrainer
+    out = {}
+
+    def init(U, I, K):
+        rs = np.random.RandomState(4321)
+        return rs.uniform(-0.1, 0.1, (U, K)) / K, rs.uniform(-0.1, 0.1, (I, K)) / K
+
+    def attempt(name, fn):
+        t0 = time.time()
+        try:
+            out[name] = fn()
+        except Exception as e:   # pragma: no cover
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        log(0, f"secondary {name}: {time.time()-t0:.1f}s {out[name].get('value', out[name].get('error'))}")
+
+    def c2_bpr():
+        # BASELINE config 2: MovieLens-1M-shaped BPR K=64 fp32 (cymf/bpr.pyx:160-171), lock-free mode
+        X, K = synthetic.config_matrix("C2")
+        U, I = X.shape
+        r, c = X.nonzero()
+        perm = np.random.RandomState(5).permutation(len(r))
+        W, H = init(U, I, K)
+        t = BprTrainer(U, I, K, "sgd", 0.05, 0.01, dtype="float32", mode="throughput", device=device)
+        t.set_data(r[perm], c[perm], X.indptr, X.indices)
+        t.upload(W, H)
+        t.epochs(3)
+        p0, _ = t.stats()
+        t.set_profiling(True)
+        t.kernel_time()
+        n = 50
+        ms = _timed_epochs(lambda: t.steps(1), n, device)
+        p1, _ = t.stats()
+        k_ms, k_n, _ = t.kernel_time()
+        t.close()
+        per_epoch = (p1 - p0) / (n + 1)
+        rl = _hbm_roofline(per_epoch, 24 * K + 12, k_ms / max(k_n, 1), "bpr_step_kernel")
+        rl["timing"] = "HIP events on the kernel's stream, average launch"
+        return {"workload": f"C2: {U} x {I}, {X.nnz} interactions, K={K}, sgd, lock-free mode, one step per epoch",
+                "value": per_epoch / (ms * 1e-3), "unit": "triplet-updates/s", "ms": ms, "kernel_ms": k_ms / max(k_n, 1), "roofline": rl}
+
+    def c4_wmf():
+        # BASELINE config 4: WMF ALS K=64 on ml-20m-shaped data (cymf/wmf.pyx:150-171)
+        U, I, nnz, K, seed = synthetic.CONFIGS["C4"]
+        if scale != 1.0:
+            U, nnz = max(int(U * scale), 1000), max(int(nnz * scale), 10000)
+        rows, cols, indptr = synthetic.implicit_matrix_large(U, I, nnz, seed)
+        X = sparse.csr_matrix((np.ones(len(rows), dtype=np.float32), cols, indptr), shape=(U, I))
+        Xt = X.T.tocsr()
+        res = {}
+        for Kx in (64, 128):
+            W, H = init(U, I, Kx)
+            t = WmfTrainer(U, I, Kx, 10.0, 0.01, dtype="float32", device=device)
+            t.set_data(X.indptr, X.indices, Xt.indptr, Xt.indices)
+            t.upload(W, H)
+            ms = _timed_epochs(lambda: t.epochs(1), 5, device)
+            t.close()
+            # SURVEY.md 8d: 2 (2 K^2 nnz) Gramian + (U+I)(2/3 K^3 + 2 K^2) solve + 2 (U+I) K^2 YtY
+            flops = 2 * (2 * Kx * Kx * X.nnz) + (U + I) * (2.0 / 3.0 * Kx ** 3 + 2 * Kx * Kx) + 2 * (U + I) * Kx * Kx
+            a = flops / (ms * 1e-3)
+            res[Kx] = {"workload": f"C4: {U} x {I}, {X.nnz} entries, K={Kx}, weight 10, f32", "value": 1e3 / ms, "unit": "epochs/s", "ms": ms,
+                       "roofline": {"bound": "mfma", "achieved": a / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                                    "frac": a / MFMA_F32_PEAK, "flops_per_epoch": flops, "kernel": "wmf_row_reg_kernel (+ seg / long / YtY kernels)",
+                                    "gather_GBps": 2 * X.nnz * (4 * Kx + 4) / (ms * 1e-3) / 1e9, "traffic": None,
+                                    "timing": "device-synchronised wall time per epoch (both half-sweeps, all kernels)"}}
+        r = res[64]
+        r["k128"] = res[128]
+        return r
+
+    def c5_glove():
+        # BASELINE config 5: GloVe K=100 on a text8-shaped co-occurrence COO (cymf/glove.pyx:149-156)
+        V, _, nnz, K, seed = synthetic.CONFIGS["C5"]
+        if scale != 1.0:
+            nnz = max(int(nnz * scale), 10000)
+        X = synthetic.cooccurrence_matrix(V, nnz, seed)
+        ce, cx = X.nonzero()
+        rs = np.random.RandomState(3)
+        p = rs.permutation(len(ce))
+        ce, cx, cnt = ce[p], cx[p], X.data[p]
+        W, b = rs.uniform(-0.5, 0.5, (V, K)) / K, rs.uniform(-0.5, 0.5, (V,)) / K
+        Wc, bc = rs.uniform(-0.5, 0.5, (V, K)) / K, rs.uniform(-0.5, 0.5, (V,)) / K
+        t = GloveTrainer(V, V, K, 0.05, 10.0, 0.75, dtype="float32", mode="throughput", device=device)
+        t.set_data(ce, cx, cnt)
+        t.upload(W, b, Wc, bc)
+        ms = _timed_epochs(lambda: t.epochs(1), 5, device)
+        t.close()
+        return {"workload": f"C5: V={V}, {len(ce)} pairs, K={K}, AdaGrad lr 0.05, lock-free mode", "value": len(ce) / (ms * 1e-3),
+                "unit": "pairs/s", "ms": ms, "roofline": _hbm_roofline(len(ce), 32 * K + 44, ms, "glove_step_kernel")}
+
+    def relmf():
+        # RelMF (cymf/relmf.pyx:142-148): U*I uniform cell draws per epoch
+        U, I, K = (20000, 8000, 64) if scale == 1.0 else (2000, 800, 64)
+        rs = np.random.RandomState(1)
+        X = (rs.rand(U, I) < 0.02).astype(np.float64)
+        prop = np.maximum(X.mean(axis=0) / X.mean(axis=0).max(), 1e-5) ** 0.5
+        W, H = init(U, I, K)
+        t = RelMfTrainer(U, I, K, "sgd", 0.01, 0.01, 0.1, mode="throughput", device=device)
+        t.set_data(X, prop)
+        t.upload(W, H)
+        ms = _timed_epochs(lambda: t.epochs(1), 4, device)
+        t.close()
+        return {"workload": f"RelMF {U} x {I} dense, K={K}, sgd, {U*I} draws per epoch, lock-free mode", "value": U * I / (ms * 1e-3),
+                "unit": "draws/s", "ms": ms, "roofline": _hbm_roofline(U * I, 16 * K + 8, ms, "relmf step kernels")}
+
+    attempt("C2_bpr_k64", c2_bpr)
+    attempt("C4_wmf_k64", c4_wmf)
+    attempt("C5_glove_k100", c5_glove)
+    attempt("relmf_20000x8000_k64", relmf)
+    return out
 
 
 if __name__ == "__main__":

@@ -101,6 +101,68 @@ __global__ __launch_bounds__(256) void bpr_level_kernel(BprDev<T> d, const int32
     if (lane == 0) atomicAdd(loss_acc, (double)loss);
 }
 
+// ---------------------------------------------------------------- any K: rows streamed from memory in two passes
+// The register layouts above hold a row in at most 4 values per lane (K <= 256).  The reference takes any
+// num_components (cymf/bpr.pyx:50): wider rows run here, one wavefront per triplet, lanes striding over k --
+// pass 1 forms x and the l2 term (cymf/model.pyx:52-59), pass 2 updates component by component from the
+// pre-update values (cymf/model.pyx:78-87).  HOG = false: one conflict-free level of the exact order (`tj` never
+// negative); HOG = true: a step of the lock-free mode over the item-sorted slots (`tj` = slot_neg: -1 skipped,
+// bit 30 the hot flag), the item rows receive their deltas as float atomics so that no concurrent update is lost.
+template <typename T, int OPT, bool HOG>
+__global__ __launch_bounds__(256) void bpr_wide_kernel(BprDev<T> d, const int32_t *__restrict__ tu,
+                                                      const int32_t *__restrict__ ti, const int32_t *__restrict__ tj,
+                                                      int64_t n, double *__restrict__ loss_acc,
+                                                      unsigned long long *__restrict__ performed_acc) {
+    const int lane = lane_id();
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int K = d.K;
+    double loss_sum = 0.0;
+    unsigned long long n_done = 0;
+    for (int64_t t = wave0; t < n; t += n_waves) {
+        const int32_t jraw = tj[t];
+        if (jraw < 0) continue;                                     // skipped draw (cymf/bpr.pyx:166-167)
+        const int64_t ou = (int64_t)tu[t] * K, oi = (int64_t)ti[t] * K, oj = (int64_t)(jraw & 0x3fffffff) * K;
+        T px = 0, pl = 0;
+        for (int k = lane; k < K; k += 64) {
+            const T wv = d.W[ou + k], iv = d.H[oi + k], jv = d.H[oj + k];
+            px += wv * (iv - jv);
+            pl += wv * wv + iv * iv + jv * jv;
+        }
+        const T x = wave_sum(px), l2 = wave_sum(pl);
+        loss_sum += (double)(softplus_neg(x) + d.wd * l2);
+        const T s = inv1pexp(x);
+        for (int k = lane; k < K; k += 64) {
+            T wv = d.W[ou + k], iv = d.H[oi + k], jv = d.H[oj + k];
+            const T gw = -(s * (iv - jv) - d.wd * wv);
+            const T gi = -(s * wv - d.wd * iv);
+            const T gj = -(s * (-wv) - d.wd * jv);
+            T w0 = 0, w1 = 0, i0 = 0, i1 = 0, j0 = 0, j1 = 0;
+            if constexpr (OPT >= 1) { w0 = d.W0[ou + k]; i0 = d.H0[oi + k]; j0 = d.H0[oj + k]; }
+            if constexpr (OPT == 2) { w1 = d.W1[ou + k]; i1 = d.H1[oi + k]; j1 = d.H1[oj + k]; }
+            const T iv_old = iv, jv_old = jv;
+            opt_update<T, OPT, HOG>(d.opt, wv, w0, w1, gw);
+            opt_update<T, OPT, HOG>(d.opt, iv, i0, i1, gi);
+            opt_update<T, OPT, HOG>(d.opt, jv, j0, j1, gj);
+            d.W[ou + k] = wv;
+            if constexpr (HOG && sizeof(T) == 4) {
+                atomicAdd(reinterpret_cast<float *>(d.H) + oi + k, (float)(iv - iv_old));
+                atomicAdd(reinterpret_cast<float *>(d.H) + oj + k, (float)(jv - jv_old));
+            } else {
+                d.H[oi + k] = iv;
+                d.H[oj + k] = jv;
+            }
+            if constexpr (OPT >= 1) { d.W0[ou + k] = w0; d.H0[oi + k] = i0; d.H0[oj + k] = j0; }
+            if constexpr (OPT == 2) { d.W1[ou + k] = w1; d.H1[oi + k] = i1; d.H1[oj + k] = j1; }
+        }
+        ++n_done;
+    }
+    if (lane == 0 && n_done) {
+        atomicAdd(loss_acc, loss_sum);
+        if (performed_acc) atomicAdd(performed_acc, n_done);
+    }
+}
+
 // ---------------------------------------------------------------- EXACT: dataflow execution of the sequential order
 // One launch per level costs a launch gap per level (~6 000 per epoch on ml-1m-shaped data).  The same
 // dependence structure can be executed by ONE launch: triplet l may run as soon as the earlier triplets that
@@ -751,9 +813,24 @@ void launch_level_opt(int opt, const BprDev<T> &d, const int32_t *tu, const int3
     }
 }
 
+template <typename T, bool HOG>
+void launch_wide(int opt, const BprDev<T> &d, const int32_t *tu, const int32_t *ti, const int32_t *tj, int64_t n, double *loss,
+                 unsigned long long *perf, int64_t waves, hipStream_t s) {
+    dim3 grid((unsigned)std::max<int64_t>(1, (waves + 3) / 4)), block(256);
+    switch (opt) {
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((bpr_wide_kernel<T, CYMF_OPT_SGD, HOG>), grid, block, 0, s, d, tu, ti, tj, n, loss, perf); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((bpr_wide_kernel<T, CYMF_OPT_ADAGRAD, HOG>), grid, block, 0, s, d, tu, ti, tj, n, loss, perf); break;
+    default: hipLaunchKernelGGL((bpr_wide_kernel<T, CYMF_OPT_ADAM, HOG>), grid, block, 0, s, d, tu, ti, tj, n, loss, perf); break;
+    }
+}
+
 template <typename T>
 void launch_level(int K, int opt, const BprDev<T> &d, const int32_t *tu, const int32_t *ti, const int32_t *tj, int n,
                   double *loss, hipStream_t s) {
+    if (K > 256) {   // rows wider than the register layouts: one wavefront per triplet of the level, two passes over k
+        launch_wide<T, false>(opt, d, tu, ti, tj, n, loss, nullptr, n, s);
+        return;
+    }
 #define CALL_(R_, P_) launch_level_opt<T, R_, P_>(opt, d, tu, ti, tj, n, loss, s)
     CYMF_DISPATCH_LAYOUT(K, CALL_);
 #undef CALL_
@@ -1143,7 +1220,11 @@ int run_one_step(cymf_bpr *h) {
             }
             CYMF_HIP(hipEventRecord(p0, h->stream));
         }
-        launch_step(h->K, h->opt, d, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, cpw, h->xcd_stride, wave_ranges, waves, h->d_loss.p, h->d_performed.p, grid, h->step_pf, h->stream);
+        if (h->K > 256)   // any num_components (cymf/bpr.pyx:50): the two-pass kernel, item deltas as atomics
+            launch_wide<float, true>(h->opt, d, h->d_slot_user.p + b, h->d_slot_item.p + b, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p + b,
+                                     e - b, h->d_loss.p, h->d_performed.p, std::min<int64_t>(waves, e - b), h->stream);
+        else
+            launch_step(h->K, h->opt, d, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, cpw, h->xcd_stride, wave_ranges, waves, h->d_loss.p, h->d_performed.p, grid, h->step_pf, h->stream);
         CYMF_HIP(hipGetLastError());
         if (h->profiling) {
             CYMF_HIP(hipEventRecord(p1, h->stream));
@@ -1339,7 +1420,6 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
     if (!out) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: out is NULL");
     *out = nullptr;
     if (U <= 0 || I <= 0 || K <= 0) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: U, I, K must be positive");
-    if (K > 256) return fail(CYMF_ERR_UNSUPPORTED, "cymf_bpr_create: K=%d > 256 (4 factors per lane) is not built", K);
     if (optimizer < 0 || optimizer > 2) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: optimizer id %d", optimizer);
     if (dtype != CYMF_F32 && dtype != CYMF_F64) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: dtype %d", dtype);
     if (mode != CYMF_MODE_EXACT && mode != CYMF_MODE_THROUGHPUT) return fail(CYMF_ERR_INVALID, "cymf_bpr_create: mode %d", mode);
@@ -1372,7 +1452,7 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
         if (const char *el = getenv("CYMF_BPR_EXACT_LEVELS")) h->exact_tickets = !(el[0] == '1');
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
-        if (h->n_cu <= 0) h->exact_tickets = false;
+        if (h->n_cu <= 0 || K > 256) h->exact_tickets = false;   // K > 256: per-level launches of the two-pass kernel
         if (h->exact_tickets) {   // rows are handed between wavefronts of one kernel, across XCDs
             for (DevBuf<float> *b : {&h->f32.W, &h->f32.H, &h->f32.W0, &h->f32.W1, &h->f32.H0, &h->f32.H1}) b->fine = 2;
             for (DevBuf<double> *b : {&h->f64.W, &h->f64.H, &h->f64.W0, &h->f64.W1, &h->f64.H0, &h->f64.H1}) b->fine = 2;
@@ -1548,6 +1628,8 @@ extern "C" int cymf_bpr_sync(cymf_bpr *h) {
     CYMF_TRY(use_device(h->device));
     if (h->comm && h->overlap_exchange && h->have_params) CYMF_TRY(finish_exchange(h, false));
     CYMF_HIP(hipStreamSynchronize(h->stream));
+    // and the side stream: the next epoch's index stream and skip tests are part of the work this handle has issued
+    if (h->rng_stream) CYMF_HIP(hipStreamSynchronize(h->rng_stream));
     return 0;
 }
 

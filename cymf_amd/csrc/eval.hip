@@ -104,14 +104,18 @@ __device__ __forceinline__ bool ranks_before(double s, int32_t i, double t, int3
 }
 
 // out layout: [metric m (DCG, Recall, MAP)][ki][U]
+// WIDE = false: k <= 64, lane r keeps the candidate ranked r (four users per workgroup).  WIDE = true: any k
+// (cymf/evaluator.pyx:29 takes any list of k): the ranked list lives in LDS, one user (one wavefront) per workgroup.
+template <bool WIDE>
 __global__ void __launch_bounds__(256) eval_rank_kernel(const double *__restrict__ scores, const int32_t *__restrict__ eval_users,
                                                        int32_t n_eval, const int64_t *__restrict__ cand_off,
                                                        const int32_t *__restrict__ test_indptr, int32_t num_neg,
                                                        const double *__restrict__ prop, int32_t n_prop, int unbiased,
                                                        const int32_t *__restrict__ ks, int32_t nk, int32_t kmax,
                                                        const double *__restrict__ disc, int32_t U, double *__restrict__ out) {
+    extern __shared__ int32_t s_rank[];      // WIDE: candidate position by rank
     const int lane = lane_id();
-    const int32_t eu = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int32_t eu = __builtin_amdgcn_readfirstlane((int)(WIDE ? blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (eu >= n_eval) return;
     const int32_t u = eval_users[eu];
     const int32_t n_test = test_indptr[u + 1] - test_indptr[u];
@@ -122,6 +126,7 @@ __global__ void __launch_bounds__(256) eval_rank_kernel(const double *__restrict
     double prev_s = __builtin_inf();
     int32_t prev_i = 0x7fffffff;
     int32_t mine = -1;                       // lane r keeps the candidate position ranked r
+    int32_t ranked = 0;                      // WIDE: ranks filled in s_rank
     for (int32_t r = 0; r < rounds; ++r) {
         double bs = 0.0;
         int32_t bi = -1;
@@ -135,9 +140,11 @@ __global__ void __launch_bounds__(256) eval_rank_kernel(const double *__restrict
             if (oi >= 0 && (bi < 0 || ranks_before(os, oi, bs, bi))) { bs = os; bi = oi; }
         }
         if (bi < 0) break;                   // only NaN scores left: they never rank
-        if (lane == r) mine = bi;
+        if constexpr (WIDE) { if (lane == 0) s_rank[r] = bi; }
+        else if (lane == r) mine = bi;
         prev_s = bs;
         prev_i = bi;
+        if constexpr (WIDE) ranked = r + 1;
     }
     const double y = (mine >= 0 && mine < n_test) ? 1.0 : 0.0;
     double p = 1.0;
@@ -155,8 +162,15 @@ __global__ void __launch_bounds__(256) eval_rank_kernel(const double *__restrict
         const int32_t k = ks[ki] < rounds ? ks[ki] : rounds;
         double dcg = 0.0, rec = 0.0, ap = 0.0, run = 0.0;
         for (int32_t r = 0; r < k; ++r) {
-            const double yr = __shfl(yp, r, 64);
-            const double hit = __shfl(y, r, 64);
+            double yr, hit;
+            if constexpr (WIDE) {
+                const int32_t pos = r < ranked ? s_rank[r] : -1;
+                hit = (pos >= 0 && pos < n_test) ? 1.0 : 0.0;
+                yr = (unbiased && pos >= 0) ? hit / prop[pos < n_prop ? pos : n_prop - 1] : hit;
+            } else {
+                yr = __shfl(yp, r, 64);
+                hit = __shfl(y, r, 64);
+            }
             run += yr;                                   // cumsum(y) or cumsum(y/p)
             dcg += yr / disc[r];
             rec += yr;
@@ -312,7 +326,10 @@ extern "C" int cymf_eval_run(cymf_eval *h, const double *W, const double *H, int
         if (ks[i] < 0) return fail(CYMF_ERR_INVALID, "cymf_eval_run: negative k");
         kmax = std::max(kmax, ks[i]);
     }
-    if (kmax > 64) return fail(CYMF_ERR_UNSUPPORTED, "cymf_eval_run: k=%d > 64 (one lane per ranked position)", kmax);
+    int32_t max_test = 0;
+    for (int32_t u = 0; u < h->U; ++u) max_test = std::max(max_test, h->h_test_indptr[(size_t)u + 1] - h->h_test_indptr[(size_t)u]);
+    const int64_t rounds_max = std::min<int64_t>(kmax, (int64_t)max_test + num_negatives);
+    if (rounds_max > 40000) return fail(CYMF_ERR_UNSUPPORTED, "cymf_eval_run: a ranked list of %lld entries exceeds the CU's LDS", (long long)rounds_max);
     if (unbiased && !h->d_prop.p) return fail(CYMF_ERR_INVALID, "cymf_eval_run: unbiased metrics need the propensity vector at create");
     CYMF_TRY(use_device(h->device));
     CYMF_TRY(eval_sample(h, seed, num_negatives));
@@ -329,9 +346,18 @@ extern "C" int cymf_eval_run(cymf_eval *h, const double *W, const double *H, int
         hipLaunchKernelGGL(eval_score_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_W.p, h->d_H.p, K, h->d_eval_users.p, n_eval,
                            h->d_cand_off.p, h->d_test_indptr.p, h->d_test_indices.p, h->d_neg.p, num_negatives, h->d_scores.p);
         CYMF_HIP(hipGetLastError());
-        hipLaunchKernelGGL(eval_rank_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_scores.p, h->d_eval_users.p, n_eval,
-                           h->d_cand_off.p, h->d_test_indptr.p, num_negatives, h->d_prop.p, h->n_prop, unbiased, h->d_ks.p, nk, kmax,
-                           h->d_disc.p, h->U, h->d_out.p);
+        if (kmax <= 64) {
+            hipLaunchKernelGGL(eval_rank_kernel<false>, dim3(blocks), dim3(256), 0, h->stream, h->d_scores.p, h->d_eval_users.p, n_eval,
+                               h->d_cand_off.p, h->d_test_indptr.p, num_negatives, h->d_prop.p, h->n_prop, unbiased, h->d_ks.p, nk, kmax,
+                               h->d_disc.p, h->U, h->d_out.p);
+        } else {   // ranked list in LDS, one user per workgroup
+            const size_t smem = (size_t)std::max<int64_t>(rounds_max, 1) * sizeof(int32_t);
+            if (smem > 48 * 1024)
+                CYMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eval_rank_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(eval_rank_kernel<true>, dim3(n_eval), dim3(64), smem, h->stream, h->d_scores.p, h->d_eval_users.p, n_eval,
+                               h->d_cand_off.p, h->d_test_indptr.p, num_negatives, h->d_prop.p, h->n_prop, unbiased, h->d_ks.p, nk, kmax,
+                               h->d_disc.p, h->U, h->d_out.p);
+        }
         CYMF_HIP(hipGetLastError());
     }
     CYMF_HIP(hipMemcpyAsync(out, h->d_out.p, n_out * sizeof(double), hipMemcpyDeviceToHost, h->stream));

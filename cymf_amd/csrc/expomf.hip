@@ -60,11 +60,15 @@ __global__ __launch_bounds__(256) void expo_mu_kernel(const double *__restrict__
 __global__ __launch_bounds__(EXPO_THREADS) void expo_row_kernel(int32_t rows, int32_t cols, int K, const int32_t *__restrict__ indptr,
                                                                const int32_t *__restrict__ indices, const double *__restrict__ E,
                                                                int64_t es_row, int64_t es_col, double *__restrict__ X,
-                                                               const double *__restrict__ Y, double lam_y, double ridge) {
+                                                               const double *__restrict__ Y, double lam_y, double ridge,
+                                                               double *A_scratch) {
     extern __shared__ unsigned char smem_raw[];
     const int lda = K + 1;
-    double *A = reinterpret_cast<double *>(smem_raw);   // [K][K+1]
-    double *b = A + K * lda;                             // [K]
+    // the K x K system sits in LDS while it fits; for larger K (cymf/expomf.pyx:45 takes any num_components) in the
+    // workgroup's own slice of a global scratch buffer -- the workgroup barriers order both alike
+    double *lds = reinterpret_cast<double *>(smem_raw);
+    double *A = A_scratch ? A_scratch + (size_t)blockIdx.x * K * lda : lds;   // [K][K+1]
+    double *b = A_scratch ? lds : lds + K * lda;         // [K]
     double *tile = b + K;                                // [EXPO_TILE][K]
     double *ew = tile + EXPO_TILE * K;                   // [EXPO_TILE]
     const int tid = threadIdx.x;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(EXPO_THREADS) void expo_row_kernel(int32_t rows, in
             }
         }
         __syncthreads();
-        if (tid == 0) {   // K <= 128: the O(K^2) substitutions on one thread are noise next to the O(cols K^2) Gramian
+        if (tid == 0) {   // the O(K^2) substitutions on one thread are noise next to the O(cols K^2) Gramian
             for (int c = 0; c < K; ++c) {
                 double s = b[c];
                 for (int r = 0; r < c; ++r) s -= A[c * lda + r] * b[r];
@@ -150,6 +154,7 @@ struct cymf_expomf {
     double lam_y = 1.0, wd = 0.01;
     hipStream_t stream = nullptr;
     DevBuf<double> W, H, E, mu;
+    DevBuf<double> A_wide;   // K > ~130: per-workgroup systems of expo_row_kernel (workgroup-private scratch)
     DevBuf<int32_t> d_indptr, d_indices, d_tindptr, d_tindices;
     bool have_data = false, have_params = false;
 };
@@ -158,7 +163,7 @@ extern "C" int cymf_expomf_create(cymf_expomf **out, int32_t U, int32_t I, int32
     if (!out) return fail(CYMF_ERR_INVALID, "cymf_expomf_create: out is NULL");
     *out = nullptr;
     if (U <= 0 || I <= 0 || K <= 0) return fail(CYMF_ERR_INVALID, "cymf_expomf_create: U, I, K must be positive");
-    if (K > 128) return fail(CYMF_ERR_UNSUPPORTED, "cymf_expomf_create: K=%d > 128 (the K x K system is LDS-resident)", K);
+    if ((int64_t)K * K > ((int64_t)1 << 26)) return fail(CYMF_ERR_UNSUPPORTED, "cymf_expomf_create: K=%d: a K x K system per workgroup beyond 2^26 entries", K);
     if (!(lam_y > 0) || !(weight_decay > 0)) return fail(CYMF_ERR_INVALID, "cymf_expomf_create: lam_y and weight_decay must be positive");
     if ((uint64_t)U * (uint64_t)I > (1ull << 32)) return fail(CYMF_ERR_UNSUPPORTED, "cymf_expomf_create: the dense %d x %d exposure matrix is not a realistic input", U, I);
     CYMF_TRY(use_device(device));
@@ -217,7 +222,14 @@ extern "C" int cymf_expomf_epochs(cymf_expomf *h, int32_t n_epochs) {
     CYMF_TRY(use_device(h->device));
     const int K = h->K;
     const double coef = std::sqrt(h->lam_y / 2.0 * M_PI);          // expomf.pyx:141, evaluated left to right
-    const size_t smem = sizeof(double) * ((size_t)K * (K + 1) + K + (size_t)EXPO_TILE * K + EXPO_TILE);
+    size_t smem = sizeof(double) * ((size_t)K * (K + 1) + K + (size_t)EXPO_TILE * K + EXPO_TILE);
+    double *scratch = nullptr;
+    const int grid_u = std::min(h->U, smem > 160 * 1024 ? 1024 : 4096), grid_i = std::min(h->I, smem > 160 * 1024 ? 1024 : 4096);
+    if (smem > 160 * 1024) {   // does not fit the CU's LDS: global slices
+        CYMF_TRY(h->A_wide.alloc((size_t)std::max(grid_u, grid_i) * K * (K + 1)));
+        scratch = h->A_wide.p;
+        smem = sizeof(double) * ((size_t)K + (size_t)EXPO_TILE * K + EXPO_TILE);
+    }
     if (smem > 48 * 1024)
         CYMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(expo_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     for (int32_t e = 0; e < n_epochs; ++e) {
@@ -225,10 +237,10 @@ extern "C" int cymf_expomf_epochs(cymf_expomf *h, int32_t n_epochs) {
                            h->U, h->I, K, h->lam_y, coef);
         hipLaunchKernelGGL(expo_mark_kernel, dim3(std::max(1, std::min(h->U / 4 + 1, 1024))), dim3(256), 0, h->stream, h->d_indptr.p,
                            h->d_indices.p, h->E.p, h->U, h->I);
-        hipLaunchKernelGGL(expo_row_kernel, dim3(std::min(h->U, 4096)), dim3(EXPO_THREADS), smem, h->stream, h->U, h->I, K, h->d_indptr.p,
-                           h->d_indices.p, h->E.p, (int64_t)h->I, (int64_t)1, h->W.p, h->H.p, h->lam_y, h->wd / h->lam_y);
-        hipLaunchKernelGGL(expo_row_kernel, dim3(std::min(h->I, 4096)), dim3(EXPO_THREADS), smem, h->stream, h->I, h->U, K, h->d_tindptr.p,
-                           h->d_tindices.p, h->E.p, (int64_t)1, (int64_t)h->I, h->H.p, h->W.p, h->lam_y, h->wd / h->lam_y);
+        hipLaunchKernelGGL(expo_row_kernel, dim3(grid_u), dim3(EXPO_THREADS), smem, h->stream, h->U, h->I, K, h->d_indptr.p,
+                           h->d_indices.p, h->E.p, (int64_t)h->I, (int64_t)1, h->W.p, h->H.p, h->lam_y, h->wd / h->lam_y, scratch);
+        hipLaunchKernelGGL(expo_row_kernel, dim3(grid_i), dim3(EXPO_THREADS), smem, h->stream, h->I, h->U, K, h->d_tindptr.p,
+                           h->d_tindices.p, h->E.p, (int64_t)1, (int64_t)h->I, h->H.p, h->W.p, h->lam_y, h->wd / h->lam_y, scratch);
         hipLaunchKernelGGL(expo_mu_kernel, dim3((h->I + 255) / 256), dim3(256), 0, h->stream, h->E.p, h->mu.p, h->U, h->I, 1.0, 1.0);
         CYMF_HIP(hipGetLastError());
     }

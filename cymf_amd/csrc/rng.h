@@ -21,13 +21,16 @@ struct RngState {
 class DeviceRng {
   public:
     ~DeviceRng();
-    // range in [1, 2^32-1]; parallel = use the chunked generator (the one-workgroup walker still serves
+    // range in [1, 2^62].  Below 2^32: 32-bit draws (generate); from 2^32 on: 64-bit draws by the one-lane walker
+    // (generate64; libstdc++'s non-Lemire branches).  parallel = use the chunked generator (the one-workgroup walker still serves
     // ranges whose Lemire rejection rate exceeds ~8 %: the per-chunk rejection list would outgrow 2 MB)
     int init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel = false);
     // Discards n_skip draws, then writes the next n draws to d_out[0..n) (device pointer), in
     // stream order on `s`.  Asynchronous; the stream position is settled lazily (finalize).
     int generate(int64_t n_skip, int64_t n, uint32_t *d_out, hipStream_t s);
-    uint64_t range() const { return range_; }
+    int generate64(int64_t n_skip, int64_t n, uint64_t *d_out, hipStream_t s);   // streams with range >= 2^32 only
+    bool wide() const { return wide_; }
+    uint64_t range() const { return wide_ ? urange_ + 1 : range_; }
     bool parallel() const { return parallel_; }
 
   private:
@@ -36,7 +39,9 @@ class DeviceRng {
     int ensure_states(int64_t last_chunk, hipStream_t s);
 
     DevBuf<RngState> st_;
-    uint32_t range_ = 0, thr_ = 0;
+    uint32_t range_ = 0, thr_ = 0;      // (wide: range and Lemire threshold of the HIGH part)
+    bool wide_ = false;
+    uint64_t urange_ = 0;               // wide: range - 1
     bool parallel_ = false;
     int64_t rej_cap_ = 0;               // rejection-list entries per chunk
     // parallel mode

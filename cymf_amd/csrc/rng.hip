@@ -158,6 +158,83 @@ __global__ __launch_bounds__(RNG_THREADS) void rng_generate_kernel(RngState *st,
     }
 }
 
+// ---------------------------------------------------------------- ranges of 2^32 and more (64-bit draws)
+// RelMF draws cells from UniformGenerator(0, U*I) on `long` (cymf/relmf.pyx:128), and libstdc++ leaves the Lemire
+// branch once the range exceeds the generator's 32 bits (bits/uniform_int_dist.h:325-347):
+//   range == 2^32 : one raw word is the draw;
+//   range  > 2^32 : do { tmp = 2^32 * D(0, urange >> 32)(g); ret = tmp + g(); } while (ret > urange || ret < tmp),
+//                   urange = range - 1, the inner draw D(0, hi_max) being the Lemire branch on hi_max + 1 < 2^32.
+// A draw consumes a data-dependent number of raw words, so the block of 624 words is regenerated by the workgroup as
+// above and then walked by ONE lane as a two-state machine (need high part / need low word).  A launch ends on a
+// completed draw, so no state beyond the generator's own survives it.  Slow by design (~10^8 words/s): these ranges
+// mean a dense X of more than 4 G cells, which the reference could not train in hours either.
+__global__ __launch_bounds__(RNG_THREADS) void rng_generate_wide_kernel(RngState *st, uint64_t urange, uint32_t range_hi,
+                                                                       uint32_t thr_hi, int64_t n_skip, int64_t n_out,
+                                                                       uint64_t *__restrict__ out) {
+    __shared__ uint32_t buf[2][MT_N];
+    __shared__ uint32_t s_idx;
+    __shared__ long long s_remaining, s_produced;
+    __shared__ unsigned long long s_raw;
+    const int tid = threadIdx.x;
+    int cur = 0;
+    for (int k = tid; k < MT_N; k += RNG_THREADS) buf[0][k] = st->mt[k];
+    if (tid == 0) { s_idx = st->idx; s_raw = st->raw_consumed; s_remaining = n_skip + n_out; s_produced = 0; }
+    __syncthreads();
+    const bool direct = urange == 0xffffffffull;   // range == 2^32
+    bool have_hi = false;                            // lane 0's machine state
+    uint64_t tmp = 0;
+    while (s_remaining > 0) {                        // uniform: s_remaining is read after a barrier
+        if (s_idx == MT_N) {
+            const uint32_t *c = buf[cur];
+            uint32_t *nx = buf[cur ^ 1];
+            if (tid < 227) nx[tid] = c[tid + MT_M] ^ mt_mix(c[tid], c[tid + 1]);
+            __syncthreads();
+            if (tid < 227) { int k = tid + 227; nx[k] = nx[k - 227] ^ mt_mix(c[k], c[k + 1]); }
+            __syncthreads();
+            if (tid < 170) { int k = tid + 454; nx[k] = nx[k - 227] ^ mt_mix(c[k], k == MT_N - 1 ? nx[0] : c[k + 1]); }
+            __syncthreads();
+            cur ^= 1;
+            if (tid == 0) s_idx = 0;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const uint32_t *c = buf[cur];
+            uint32_t idx = s_idx;
+            long long remaining = s_remaining, produced = s_produced;
+            unsigned long long raw = s_raw;
+            while (idx < MT_N && remaining > 0) {
+                const uint32_t w = mt_temper(c[idx++]);
+                ++raw;
+                uint64_t ret;
+                if (direct) {
+                    ret = w;
+                } else if (!have_hi) {
+                    const uint64_t p = (uint64_t)w * (uint64_t)range_hi;
+                    if ((uint32_t)p < thr_hi) continue;          // Lemire redraw of the high part
+                    tmp = (p >> 32) << 32;
+                    have_hi = true;
+                    continue;
+                } else {
+                    have_hi = false;
+                    ret = tmp + w;
+                    if (ret > urange || ret < tmp) continue;     // the pair is rejected as a whole
+                }
+                if (produced >= n_skip) out[produced - n_skip] = ret;
+                ++produced;
+                --remaining;
+            }
+            s_idx = idx; s_remaining = remaining; s_produced = produced; s_raw = raw;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < MT_N; k += RNG_THREADS) st->mt[k] = buf[cur][k];
+    if (tid == 0) {
+        st->idx = s_idx;
+        st->raw_consumed = s_raw;
+        st->draws += (uint64_t)s_produced;
+    }
+}
+
 // ---------------------------------------------------------------- parallel mode
 // Jump ahead by J = MT_JUMP_WORDS raw words: state(n+J) = XOR over the set bits k of g of
 // state(n+k), evaluated on the recurrence's own word sequence x (x_0..x_623 = state):
@@ -320,11 +397,19 @@ DeviceRng::~DeviceRng() {
 }
 
 int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel) {
-    if (range < 1 || range > 0xffffffffull)
-        return fail(CYMF_ERR_UNSUPPORTED,
-                    "index stream range %llu outside [1, 2^32-1] (the reference densifies X for RelMF, "
-                    "so U*I >= 2^32 cells is not a realistic input)", (unsigned long long)range);
+    if (range < 1 || range > ((uint64_t)1 << 62))
+        return fail(CYMF_ERR_INVALID, "index stream range %llu outside [1, 2^62]", (unsigned long long)range);
     CYMF_TRY(st_.alloc(1));
+    if (range > 0xffffffffull) {   // 64-bit draws: the one-lane walker (rng_generate_wide_kernel)
+        wide_ = true;
+        urange_ = range - 1;
+        range_ = (uint32_t)((urange_ >> 32) + 1);            // range of the high part D(0, urange >> 32); 1 when range == 2^32
+        thr_ = (uint32_t)(0u - range_) % range_;
+        parallel_ = false;
+        hipLaunchKernelGGL(rng_seed_kernel, dim3(1), dim3(64), 0, s, st_.p, seed);
+        CYMF_HIP(hipGetLastError());
+        return 0;
+    }
     range_ = (uint32_t)range;
     thr_ = (uint32_t)(0u - range_) % range_;   // (2^32 - range) mod range, bits/uniform_int_dist.h:260
     hipLaunchKernelGGL(rng_seed_kernel, dim3(1), dim3(64), 0, s, st_.p, seed);
@@ -448,8 +533,18 @@ int DeviceRng::generate_parallel(int64_t n_total, int64_t n_skip, uint32_t *d_ou
     return 0;
 }
 
+int DeviceRng::generate64(int64_t n_skip, int64_t n, uint64_t *d_out, hipStream_t s) {
+    if (!st_.p || !wide_) return fail(CYMF_ERR_INVALID, "DeviceRng::generate64 needs a stream initialised with range >= 2^32");
+    if (n_skip < 0 || n < 0) return fail(CYMF_ERR_INVALID, "negative draw count");
+    if (n_skip + n == 0) return 0;
+    hipLaunchKernelGGL(rng_generate_wide_kernel, dim3(1), dim3(RNG_THREADS), 0, s, st_.p, urange_, range_, thr_, n_skip, n, d_out);
+    CYMF_HIP(hipGetLastError());
+    return 0;
+}
+
 int DeviceRng::generate(int64_t n_skip, int64_t n, uint32_t *d_out, hipStream_t s) {
     if (!st_.p) return fail(CYMF_ERR_INVALID, "DeviceRng::generate before init");
+    if (wide_) return fail(CYMF_ERR_INVALID, "DeviceRng::generate: this stream draws 64-bit values (generate64)");
     if (n_skip < 0 || n < 0) return fail(CYMF_ERR_INVALID, "negative draw count");
     if (n_skip + n == 0) return 0;
     if (parallel_) return generate_parallel(n_skip + n, n_skip, d_out, s);
@@ -469,6 +564,13 @@ extern "C" int cymf_rng_fill_uniform(int device, uint32_t seed, uint64_t range, 
     DeviceRng rng;
     CYMF_TRY(rng.init(seed, range, nullptr, /*parallel=*/skip + n >= (int64_t)4 << 20));
     if (n == 0) return 0;
+    if (rng.wide()) {   // range >= 2^32: 64-bit draws straight into the output type
+        DevBuf<uint64_t> w;
+        CYMF_TRY(w.alloc((size_t)n));
+        CYMF_TRY(rng.generate64(skip, n, w.p, nullptr));
+        CYMF_HIP(hipMemcpy(out, w.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+        return 0;
+    }
     DevBuf<uint32_t> d32;
     DevBuf<int64_t> d64;
     CYMF_TRY(d32.alloc((size_t)n));

@@ -100,6 +100,49 @@ __global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const uint32_t 
     if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
 }
 
+// any K (cymf/relmf.pyx:42 takes any num_components): rows wider than the register layouts (K > 256) are streamed from
+// memory in two passes, lanes striding over k -- pass 1 the prediction and the l2 term, pass 2 the element-wise update.
+template <typename T, int OPT, bool HOG>
+__global__ __launch_bounds__(256) void relmf_wide_kernel(RelDev<T> d, const uint32_t *__restrict__ cells, int64_t n,
+                                                        double *__restrict__ loss_acc) {
+    const int lane = lane_id();
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int K = d.K;
+    double loss_sum = 0.0;
+    for (int64_t s = wave0; s < n; s += n_waves) {
+        const uint32_t cell = cells[s];
+        const int64_t u = cell / (uint32_t)d.I, i = cell % (uint32_t)d.I;
+        const T r = d.X[u * d.I + i], p = d.prop[i];
+        const int64_t ou = u * K, oi = i * K;
+        T py = 0, pl = 0;
+        for (int k = lane; k < K; k += 64) {
+            const T wv = d.W[ou + k], hv = d.H[oi + k];
+            py += wv * hv;
+            pl += wv * wv + hv * hv;
+        }
+        const T y = wave_sum(py), l2 = wave_sum(pl);
+        const T qq = r / (p >= d.clip ? p : d.clip);
+        loss_sum += (double)(qq * (1 - y) * (1 - y) + (1 - qq) * y * y + d.wd * l2);
+        const T c = qq * (1 - y) + (1 - qq) * (0 - y);
+        for (int k = lane; k < K; k += 64) {
+            T wv = d.W[ou + k], hv = d.H[oi + k];
+            const T gw = -(c * hv) + d.wd * wv;
+            const T gh = -(c * wv) + d.wd * hv;
+            T w0 = 0, w1 = 0, h0 = 0, h1 = 0;
+            if constexpr (OPT >= 1) { w0 = d.W0[ou + k]; h0 = d.H0[oi + k]; }
+            if constexpr (OPT == 2) { w1 = d.W1[ou + k]; h1 = d.H1[oi + k]; }
+            opt_update<T, OPT, HOG>(d.opt, wv, w0, w1, gw);
+            opt_update<T, OPT, HOG>(d.opt, hv, h0, h1, gh);
+            d.W[ou + k] = wv;
+            d.H[oi + k] = hv;
+            if constexpr (OPT >= 1) { d.W0[ou + k] = w0; d.H0[oi + k] = h0; }
+            if constexpr (OPT == 2) { d.W1[ou + k] = w1; d.H1[oi + k] = h1; }
+        }
+    }
+    if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
+}
+
 // ================================================================== GloVe
 template <typename T>
 struct GloveDev {
@@ -167,6 +210,55 @@ __global__ __launch_bounds__(256) void glove_kernel(GloveDev<T> d, const int32_t
         h.store(d.H + ox, K, lane);
         aw.store(d.aW + oc, K, lane);
         ah.store(d.aH + ox, K, lane);
+        if (lane == 0) {
+            d.bW[c] = bw - d.lr * diff * sbw;
+            d.bH[x] = bh - d.lr * diff * sbh;
+            d.abW[c] = abw + (T)K * g2;
+            d.abH[x] = abh + (T)K * g2;
+        }
+    }
+    if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
+}
+
+// any K (cymf/glove.pyx:57): the two-pass form of glove_kernel for rows wider than the register layouts (K > 256)
+template <typename T>
+__global__ __launch_bounds__(256) void glove_wide_kernel(GloveDev<T> d, const int32_t *__restrict__ central,
+                                                        const int32_t *__restrict__ context,
+                                                        const T *__restrict__ counts, int64_t n,
+                                                        double *__restrict__ loss_acc) {
+    const int lane = lane_id();
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int K = d.K;
+    double loss_sum = 0.0;
+    for (int64_t s = wave0; s < n; s += n_waves) {
+        const int64_t c = central[s], x = context[s];
+        const T cnt = counts[s];
+        const int64_t oc = c * K, ox = x * K;
+        const T bw = d.bW[c], bh = d.bH[x], abw = d.abW[c], abh = d.abH[x];
+        T pd = 0;
+        for (int k = lane; k < K; k += 64) pd += d.W[oc + k] * d.H[ox + k];
+        T diff = wave_sum(pd);
+        diff += bw + bh;
+        diff -= flog(cnt);
+        const T tmp = diff;
+        const T f = fpow(cnt / d.x_max, d.alpha);
+        diff *= f < (T)1 ? f : (T)1;
+        loss_sum += (double)((T)0.5 * diff * tmp);
+        const T g2 = diff * diff;
+        T pbw = 0, pbh = 0;
+        for (int k = lane; k < K; k += 64) {
+            pbw += (T)1 / fsqrt(abw + (T)(k + 1) * g2);   // the K-fold bias update in closed form (cymf/model.pyx:195-204)
+            pbh += (T)1 / fsqrt(abh + (T)(k + 1) * g2);
+            T wv = d.W[oc + k], hv = d.H[ox + k], aw = d.aW[oc + k], ah = d.aH[ox + k];
+            const T gw = diff * hv, gh = diff * wv;
+            aw += gw * gw;
+            wv -= d.lr * gw / fsqrt(aw);
+            ah += gh * gh;
+            hv -= d.lr * gh / fsqrt(ah);
+            d.W[oc + k] = wv; d.H[ox + k] = hv; d.aW[oc + k] = aw; d.aH[ox + k] = ah;
+        }
+        const T sbw = wave_sum(pbw), sbh = wave_sum(pbh);
         if (lane == 0) {
             d.bW[c] = bw - d.lr * diff * sbw;
             d.bH[x] = bh - d.lr * diff * sbh;
@@ -722,6 +814,16 @@ void launch_relmf_opt(int opt, const RelDev<T> &d, const uint32_t *cells, int64_
 template <typename T>
 void launch_relmf(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, double *loss, int grid,
                   hipStream_t s, bool hog = false) {
+    if (K > 256) {
+#define WIDE_(O_)                                                                                                                   \
+    do {                                                                                                                            \
+        if (hog) hipLaunchKernelGGL((relmf_wide_kernel<T, O_, true>), dim3(grid), dim3(256), 0, s, d, cells, n, loss);              \
+        else hipLaunchKernelGGL((relmf_wide_kernel<T, O_, false>), dim3(grid), dim3(256), 0, s, d, cells, n, loss);                 \
+    } while (0)
+        if (opt == CYMF_OPT_SGD) WIDE_(CYMF_OPT_SGD); else if (opt == CYMF_OPT_ADAGRAD) WIDE_(CYMF_OPT_ADAGRAD); else WIDE_(CYMF_OPT_ADAM);
+#undef WIDE_
+        return;
+    }
 #define CALL_(R_, P_)                                                                 \
     do {                                                                              \
         if (hog) launch_relmf_opt<T, R_, P_, true>(opt, d, cells, n, loss, grid, s);  \
@@ -734,6 +836,10 @@ void launch_relmf(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int
 template <typename T>
 void launch_glove(int K, const GloveDev<T> &d, const int32_t *c, const int32_t *x, const T *cnt, int64_t n,
                   double *loss, int grid, hipStream_t s) {
+    if (K > 256) {
+        hipLaunchKernelGGL((glove_wide_kernel<T>), dim3(grid), dim3(256), 0, s, d, c, x, cnt, n, loss);
+        return;
+    }
 #define CALL_(R_, P_) hipLaunchKernelGGL((glove_kernel<T, R_, P_>), dim3(grid), dim3(256), 0, s, d, c, x, cnt, n, loss)
     CYMF_DISPATCH_LAYOUT(K, CALL_);
 #undef CALL_
@@ -953,7 +1059,6 @@ extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t
     if (!out) return fail(CYMF_ERR_INVALID, "cymf_relmf_create: out is NULL");
     *out = nullptr;
     if (U <= 0 || I <= 0 || K <= 0) return fail(CYMF_ERR_INVALID, "cymf_relmf_create: U, I, K must be positive");
-    if (K > 256) return fail(CYMF_ERR_UNSUPPORTED, "cymf_relmf_create: K=%d > 256 is not built", K);
     if (optimizer < 0 || optimizer > 2 || (dtype != CYMF_F32 && dtype != CYMF_F64) ||
         (mode != CYMF_MODE_EXACT && mode != CYMF_MODE_THROUGHPUT))
         return fail(CYMF_ERR_INVALID, "cymf_relmf_create: bad optimizer/dtype/mode");
@@ -1127,7 +1232,6 @@ extern "C" int cymf_glove_create(cymf_glove **out, int32_t V, int32_t Vc, int32_
     if (!out) return fail(CYMF_ERR_INVALID, "cymf_glove_create: out is NULL");
     *out = nullptr;
     if (V <= 0 || Vc <= 0 || K <= 0) return fail(CYMF_ERR_INVALID, "cymf_glove_create: V, Vc, K must be positive");
-    if (K > 256) return fail(CYMF_ERR_UNSUPPORTED, "cymf_glove_create: K=%d > 256 is not built", K);
     if ((dtype != CYMF_F32 && dtype != CYMF_F64) || (mode != CYMF_MODE_EXACT && mode != CYMF_MODE_THROUGHPUT))
         return fail(CYMF_ERR_INVALID, "cymf_glove_create: bad dtype/mode");
     CYMF_TRY(use_device(device));

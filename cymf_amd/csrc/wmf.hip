@@ -58,6 +58,27 @@ __global__ __launch_bounds__(WMF_THREADS) void wmf_gram_kernel(const T *__restri
     }
 }
 
+// YtY for any K (cymf/wmf.pyx:142 via np.dot): a workgroup forms one 16 x 16 tile of G over a slab of rows of Y,
+// both 16-column panels staged through LDS, and adds it to G with atomics.  Used when K > 128.
+template <typename T>
+__global__ __launch_bounds__(256) void wmf_gram_wide_kernel(const T *__restrict__ Y, int64_t cols, int K, int n_kb,
+                                                           T *__restrict__ G) {
+    __shared__ T pa[16][17], pb[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int ka = (blockIdx.x / n_kb) * 16, kb = (blockIdx.x % n_kb) * 16;
+    T acc = 0;
+    for (int64_t base = (int64_t)blockIdx.y * 16; base < cols; base += (int64_t)gridDim.y * 16) {
+        __syncthreads();
+        const int64_t r = base + ty;
+        pa[ty][tx] = (r < cols && ka + tx < K) ? Y[r * K + ka + tx] : (T)0;
+        pb[ty][tx] = (r < cols && kb + tx < K) ? Y[r * K + kb + tx] : (T)0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += pa[q][ty] * pb[q][tx];
+    }
+    if (ka + ty < K && kb + tx < K && acc != (T)0) atomicAdd(G + (int64_t)(ka + ty) * K + kb + tx, acc);
+}
+
 template <typename T>
 __global__ void wmf_add_diag_kernel(T *G, int K, T lambda) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,16 +131,19 @@ __device__ void chol_solve_lds(T *A, T *b, T *dg, int K, int lda) {
     __syncthreads();
 }
 
-// Generic row kernel (any K <= 128, f32 or f64).
+// Generic row kernel (any K, f32 or f64).  The K x K system lives in LDS while it fits (A_scratch == nullptr); for
+// larger K (cymf/wmf.pyx:44 takes any num_components) each workgroup works in its own K x (K+1) slice of a global
+// scratch buffer instead -- same code, the workgroup barriers order its global accesses as they order the LDS ones.
 template <typename T>
 __global__ __launch_bounds__(WMF_THREADS) void wmf_row_kernel(int32_t rows, int K, const int32_t *__restrict__ indptr,
                                                              const int32_t *__restrict__ indices,
                                                              T *__restrict__ X, const T *__restrict__ Y,
-                                                             const T *__restrict__ A0, T weight) {
+                                                             const T *__restrict__ A0, T weight, T *A_scratch) {
     extern __shared__ unsigned char smem_raw[];
     const int lda = K + 1;
-    T *A = reinterpret_cast<T *>(smem_raw);   // [K][K+1]
-    T *b = A + K * lda;                        // [K]
+    T *lds = reinterpret_cast<T *>(smem_raw);
+    T *A = A_scratch ? A_scratch + (size_t)blockIdx.x * K * lda : lds;   // [K][K+1]
+    T *b = A_scratch ? lds : lds + K * lda;    // [K]
     T *dg = b + K;                             // [K] Cholesky diagonal
     T *tile = dg + K;                          // [WMF_TILE][K]
     const int tid = threadIdx.x;
@@ -722,6 +746,9 @@ using namespace cymf;
 template <typename T>
 struct WmfStore {
     DevBuf<T> W, H, G;
+    DevBuf<T> A_wide;   // K > ~130 (f64) / ~190 (f32): per-workgroup K x (K+1) systems of the generic row kernel
+    // workgroup-private scratch, every element written before it is read inside one kernel by the same CU: plain cached memory
+    WmfStore() { A_wide.fine = 0; }
 };
 
 namespace cymf {
@@ -818,6 +845,10 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             }
 #undef WMF_GRAM_
         }
+    } else if (K > 128) {   // YtY for any K: 16 x 16 output tiles over slabs of rows
+        const int n_kb = (K + 15) / 16;
+        const int slabs = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)cols + 255) / 256, 64));
+        hipLaunchKernelGGL(wmf_gram_wide_kernel<T>, dim3(n_kb * n_kb, slabs), dim3(256), 0, h->stream, Y, (int64_t)cols, K, n_kb, st.G.p);
     } else {   // YtY + lambda I  (wmf.pyx:142-143)
         int grid = (int)std::min<int64_t>(((int64_t)cols + WMF_TILE - 1) / WMF_TILE, 1024);
         size_t smem = sizeof(T) * WMF_TILE * K;
@@ -892,9 +923,17 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
     }
     if (!mfma) {
         size_t smem = sizeof(T) * ((size_t)K * (K + 1) + 2 * K + (size_t)WMF_TILE * K);
+        T *scratch = nullptr;
+        int grid_g = grid;
+        if (smem > 160 * 1024) {   // the system does not fit the CU's LDS: one global K x (K+1) slice per workgroup
+            grid_g = (int)std::max<int64_t>(1, std::min<int64_t>(my_rows, 256 * 4));
+            CYMF_TRY(st.A_wide.alloc((size_t)grid_g * K * (K + 1)));
+            scratch = st.A_wide.p;
+            smem = sizeof(T) * (2 * (size_t)K + (size_t)WMF_TILE * K);
+        }
         CYMF_TRY(allow_lds(wmf_row_kernel<T>, smem));
         if (my_rows > 0)
-            hipLaunchKernelGGL(wmf_row_kernel<T>, dim3(grid), dim3(WMF_THREADS), smem, h->stream, my_rows, K, ip, ix, X, Y, st.G.p, (T)h->weight);
+            hipLaunchKernelGGL(wmf_row_kernel<T>, dim3(grid_g), dim3(WMF_THREADS), smem, h->stream, my_rows, K, ip, ix, X, Y, st.G.p, (T)h->weight, scratch);
     }
     CYMF_HIP(hipGetLastError());
     if (h->comm && !h->bounds[side].empty())   // every rank ends the half-sweep with the whole updated table
@@ -907,7 +946,7 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     if (!out) return fail(CYMF_ERR_INVALID, "cymf_wmf_create: out is NULL");
     *out = nullptr;
     if (U <= 0 || I <= 0 || K <= 0) return fail(CYMF_ERR_INVALID, "cymf_wmf_create: U, I, K must be positive");
-    if (K > 128) return fail(CYMF_ERR_UNSUPPORTED, "cymf_wmf_create: K=%d > 128 (the K x K system is LDS-resident)", K);
+    if ((int64_t)K * K > ((int64_t)1 << 26)) return fail(CYMF_ERR_UNSUPPORTED, "cymf_wmf_create: K=%d: a K x K system per workgroup beyond 2^26 entries", K);
     if (dtype != CYMF_F32 && dtype != CYMF_F64) return fail(CYMF_ERR_INVALID, "cymf_wmf_create: dtype %d", dtype);
     CYMF_TRY(use_device(device));
     cymf_wmf *h = new cymf_wmf();

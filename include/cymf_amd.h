@@ -70,8 +70,10 @@ int cymf_device_seam_probe(int device, int memtype, int rounds, int64_t *stale_o
 /* ---------------------------------------------------------------- negative-sample index stream
  * UniformGenerator(a=0, b=range, seed): cymf/math.pyx:12-18, cymf/math.pxd:31-39
  * = std::mt19937(seed) + std::uniform_int_distribution<long>(0, range-1) (libstdc++-11:
- * Lemire rejection on 32-bit words).  Generated ON THE DEVICE; bit-exact.
- * Fills out[0..n) with draws [skip, skip+n) of the stream.  range must be in [1, 2^32-1]. */
+ * Lemire rejection on 32-bit words below 2^32; one raw word at 2^32; high part + low word with rejection above,
+ * bits/uniform_int_dist.h:281-352 -- RelMF draws cells from range U*I, cymf/relmf.pyx:128).
+ * Generated ON THE DEVICE; bit-exact.  Fills out[0..n) with draws [skip, skip+n) of the stream.
+ * range must be in [1, 2^62]. */
 int cymf_rng_fill_uniform(int device, uint32_t seed, uint64_t range, int64_t n, int64_t skip,
                           int64_t *out);
 
@@ -105,6 +107,8 @@ int cymf_bpr_epochs(cymf_bpr *h, int32_t n_epochs, double *loss_out);
 /* THROUGHPUT mode: advance n_steps steps (wrapping over epoch boundaries); asynchronous
  * w.r.t. the host until cymf_bpr_sync / download.  loss_sum_out (may be NULL) forces a sync. */
 int cymf_bpr_steps(cymf_bpr *h, int32_t n_steps, double *loss_sum_out);
+/* waits for everything the handle has issued: the step stream and the side stream that prepares the next epoch's
+ * negatives (index stream, skip tests) */
 int cymf_bpr_sync(cymf_bpr *h);
 /* counters since create: performed triplet updates, skipped draws (cymf/bpr.pyx:166-167) */
 int cymf_bpr_stats(cymf_bpr *h, int64_t *performed, int64_t *skipped);

@@ -31,3 +31,14 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "triplet-updates/s" and c["sample"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    # whole epochs inside the timed window, the side-stream work with them
+    assert d["epochs_covered"] * d["config"]["steps_per_epoch"] == d["steps"] and "scaling_note" in d
+    assert r["frac_min_traffic"] < r["frac"] and "traffic_source" in r and "basis" in r
+    # BASELINE.json's other configs, driver-visible
+    sec = d["secondary"]
+    assert set(sec) == {"C2_bpr_k64", "C4_wmf_k64", "C5_glove_k100", "relmf_20000x8000_k64"}
+    for name, e in sec.items():
+        assert "error" not in e, (name, e)
+        assert e["value"] > 0 and e["ms"] > 0 and e["unit"] and e["workload"]
+        assert e["roofline"]["bound"] in ("hbm", "mfma") and 0 < e["roofline"]["frac"] < 1.5 and e["roofline"]["peak"] > 0
+    assert sec["C4_wmf_k64"]["roofline"]["bound"] == "mfma" and sec["C4_wmf_k64"]["k128"]["ms"] > 0

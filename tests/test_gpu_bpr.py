@@ -227,7 +227,7 @@ def test_throughput_steps_cover_each_triplet_once():
 def test_invalid_inputs_fail_loudly():
     from cymf_amd import _lib
     with pytest.raises(_lib.CymfError):
-        BprTrainer(10, 10, 300)                       # K > 256 not built
+        BprTrainer(10, 10, 0)                         # K must be positive
     t = BprTrainer(4, 5, 8)
     with pytest.raises(_lib.CymfError):               # item index out of range
         t.set_data([0], [7], [0, 1, 1, 1, 1], [7])
@@ -322,3 +322,29 @@ def test_step_kernel_boundaries_every_slot_exactly_once(K, opt, item_aligned, mo
         assert np.array_equal(got[touches == 0], np.zeros_like(got[touches == 0]))
         assert (np.abs(got) <= touches[:, None] * lr * 0.5 * 0.2 / K * 1.05 + 1e-12).all()   # |s| <= ~1/2, |row entries| <= 0.1/K (x2 for a difference)
     assert touchH[7] >= 190 and lossless.sum() > I - 40
+
+
+@pytest.mark.parametrize("opt,lr", [("sgd", 0.05), ("adagrad", 0.05), ("adam", 0.002)])
+@pytest.mark.parametrize("K", [300, 513])
+def test_any_num_components_exact_vs_oracle(K, opt, lr):
+    """cymf/bpr.pyx:50 takes any num_components.  Beyond the register layouts (K > 256) the rows are streamed in two
+    passes (bpr_wide_kernel), one launch per level of the sequential order: same parity bar as the fixtures."""
+    X = synthetic.implicit_matrix(120, 90, 1500, 77)
+    W, H, _ = oracle.bpr_fit(X, K, opt, lr, 0.01, 2)
+    m = BPR(K, lr, opt, 0.01)
+    m.fit(X, num_epochs=2, num_threads=1, verbose=False, dtype="float64")
+    assert rel_fro(m.W, W) <= 1e-10 and rel_fro(m.H, H) <= 1e-10
+    m32 = BPR(K, lr, opt, 0.01)
+    m32.fit(X, num_epochs=2, num_threads=1, verbose=False, dtype="float32")
+    assert rel_fro(m32.W, W) <= 1e-4 and rel_fro(m32.H, H) <= 1e-4
+
+
+def test_any_num_components_throughput_mode():
+    X = synthetic.implicit_matrix(3000, 2000, 150000, 21)
+    K = 320
+    mt = BPR(K, 0.05, "sgd", 0.01)
+    mt.fit(X, num_epochs=6, num_threads=8, verbose=False)
+    W, H, losses = _oracle_in_bucketed_order(X, K, "sgd", 0.05, 0.01, 6)
+    assert mt.performed_ + mt.skipped_ == 6 * X.nnz
+    np.testing.assert_allclose(mt.losses[-2:], losses[-2:], rtol=5e-2)
+    assert abs(np.linalg.norm(mt.W) / np.linalg.norm(W) - 1) < 0.1 and abs(np.linalg.norm(mt.H) / np.linalg.norm(H) - 1) < 0.1

@@ -81,13 +81,22 @@ def test_evaluator_matches_restatement():
     got2 = Evaluator(Xte, Xtr, k=[1, 5]).evaluate(W, H, seed=7)
     assert got2["Recall@5"] == pytest.approx(_restated(Xte, Xtr, W, H, seed=7)["Recall@5"], rel=1e-12)
     assert set(got2) == {f"{m}@{k}" for m in ("DCG", "Recall", "MAP") for k in (1, 5)}
-    # IPS variants (propensities indexed by candidate position, evaluator.pyx:92), several k incl. k > 64 refused
+    # IPS variants (propensities indexed by candidate position, evaluator.pyx:92), several k
     gotu = UnbiasedEvaluator(Xte, Xtr, k=[3, 10]).evaluate(W, H)
     wantu = _restated(Xte, Xtr, W, H, k=[3, 10], unbiased=True)
     for key in wantu:
         assert gotu[key] == pytest.approx(wantu[key], rel=1e-12), key
-    with pytest.raises(RuntimeError):
-        Evaluator(Xte, Xtr, k=65).evaluate(W, H)
+    # k > 64 (cymf/evaluator.pyx:29 takes any k): the ranked list moves from the lanes into LDS; k beyond the
+    # candidate count ranks everything
+    gotw = Evaluator(Xte, Xtr, k=[5, 65, 100, 5000]).evaluate(W, H)
+    wantw = _restated(Xte, Xtr, W, H, k=[5, 65, 100, 5000])
+    for key in wantw:
+        assert gotw[key] == pytest.approx(wantw[key], rel=1e-12), key
+    assert gotw["Recall@5"] == pytest.approx(want["Recall@5"], rel=1e-12) and gotw["Recall@5000"] > 0.99
+    gotwu = UnbiasedEvaluator(Xte, Xtr, k=[80]).evaluate(W, H)
+    wantwu = _restated(Xte, Xtr, W, H, k=[80], unbiased=True)
+    for key in wantwu:
+        assert gotwu[key] == pytest.approx(wantwu[key], rel=1e-12), key
     with pytest.raises(ValueError):
         Evaluator(Xte, Xtr).evaluate(W[:-1], H)
 

@@ -16,7 +16,7 @@ def _init(U, I, K):
     return np.random.randn(U, K) * 0.01, np.random.randn(I, K) * 0.01
 
 
-@pytest.mark.parametrize("K,lam_y,wd", [(20, 1.0, 0.01), (8, 0.5, 0.1), (64, 1.0, 0.01)])
+@pytest.mark.parametrize("K,lam_y,wd", [(20, 1.0, 0.01), (8, 0.5, 0.1), (64, 1.0, 0.01), (140, 1.0, 0.01)])   # K=140: system in a global slice
 def test_expomf_vs_restatement_unpinned(K, lam_y, wd):
     X = synthetic.implicit_matrix(150, 220, 3000, 71).tolil()
     X[4] = 0                                                         # a user without positives: row of zeros (:178-182)

@@ -112,6 +112,44 @@ def test_glove_text8_shaped_vs_oracle_and_hogwild():
     assert np.isfinite(mt.W).all()
 
 
+@pytest.mark.parametrize("K", [300])
+def test_any_num_components_relmf_and_glove_vs_oracle(K):
+    """cymf/relmf.pyx:42 and cymf/glove.pyx:57 take any num_components: beyond K=256 the two-pass kernels
+    (relmf_wide_kernel / glove_wide_kernel) run the same level schedule; same parity bars."""
+    rs = np.random.RandomState(3)
+    U, I = 40, 50
+    Xd = (rs.rand(U, I) < 0.1).astype(np.float64)
+    prop = np.maximum(Xd.mean(axis=0) / Xd.mean(axis=0).max(), 1e-5) ** 0.5
+    for opt, lr in (("sgd", 0.02), ("adagrad", 0.05), ("adam", 0.002)):
+        W, H = oracle.reference_init(U, I, K)
+        om = oracle.RelMf(W, H, opt, lr, 0.01, 0.1)
+        loss = [om.epoch(Xd, prop) for _ in range(2)]
+        m = RelMF(K, 0.1, lr, opt, 0.01)
+        m.fit(Xd, num_epochs=2, num_threads=1)
+        assert _close(m.W, W, 1e-10) and _close(m.H, H, 1e-10), opt
+        assert m.losses[-1] == pytest.approx(loss[-1], rel=1e-10)
+    mt = RelMF(K, 0.1, 0.02, "sgd", 0.01)
+    mt.fit(Xd, num_epochs=2, num_threads=4)                              # lock-free mode, f32
+    assert np.isfinite(mt.W).all() and mt.losses[-1] == pytest.approx(loss[-1], rel=0.5)
+    V = 200
+    X = synthetic.cooccurrence_matrix(V, 5000, 105)
+    for dtype, tol in (("float64", 1e-10), ("float32", 1e-4)):
+        np.random.seed(6)
+        g = GloVe(K, 0.05, 0.75, 10.0)
+        g.fit(X, 2, 1, dtype=dtype)
+        np.random.seed(6)
+        W = np.random.uniform(-0.5, 0.5, (V, K)) / K
+        b = np.random.uniform(-0.5, 0.5, (V,)) / K
+        _W = np.random.uniform(-0.5, 0.5, (V, K)) / K
+        _b = np.random.uniform(-0.5, 0.5, (V,)) / K
+        ce, cx = X.nonzero()
+        ce, cx, cnt = oracle.reference_shuffle(ce, cx, X.data)
+        og = oracle.Glove(W, b, _W, _b, 0.05, 10.0, 0.75)
+        for _ in range(2):
+            og.epoch(ce, cx, cnt)
+        assert _close(g.W, (W + _W) / 2.0, tol) and _close(g.bias, b, tol), dtype
+
+
 def test_glove_rejects_bad_pairs():
     from cymf_amd import _lib
     from cymf_amd.glove import GloveTrainer
@@ -136,9 +174,11 @@ def test_wmf_vs_lapack_fixture_unpinned(K, dtype):
     assert (m.W[np.diff(X.indptr) == 0] == 0).all()                     # empty rows zeroed (wmf.pyx:154-156)
 
 
-@pytest.mark.parametrize("K", [20, 32, 64, 96, 128])
+@pytest.mark.parametrize("K", [20, 32, 64, 96, 128, 150, 200, 260])
 def test_wmf_half_sweeps_vs_oracle(K):
-    # K=20: generic kernel; multiples of 32: the MFMA Gramian kernel (1, 3, 6, 10 upper tiles)
+    # K=20: generic kernel; multiples of 32: the MFMA Gramian kernel (1, 3, 6, 10 upper tiles); K > 128 (cymf/wmf.pyx:44
+    # takes any num_components): generic kernel with the tiled YtY, the K x K system in LDS up to K=191 and in a
+    # per-workgroup global slice beyond
     X = synthetic.implicit_matrix(700, 900, 30000, 31)
     Xt = X.T.tocsr()
     W, H = oracle.reference_init(700, 900, K)

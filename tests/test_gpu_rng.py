@@ -15,13 +15,11 @@ def test_stream_vs_libstdcxx_fixture():
     checked = 0
     for key in g.files:
         seed, rng_range = (99, 100000) if key.startswith("seed99") else (1234, int(key[1:]))
-        if rng_range > 2**32 - 1:
-            continue
-        want = g[key]
+        want = g[key]     # ranges 2**32, 2**32 + 12345, 5 * 2**32 + 3 included: the non-Lemire branches of libstdc++
         got = _lib.rng_fill_uniform(seed, rng_range, len(want))
         assert np.array_equal(got, want), key
         checked += 1
-    assert checked >= 8
+    assert checked >= 11
 
 
 def test_stream_survey_known_answers():
@@ -44,9 +42,20 @@ def test_stream_block_boundaries():
         assert np.array_equal(_lib.rng_fill_uniform(7, 1000, 7, skip=n), full[n:n + 7])
 
 
+@pytest.mark.parametrize("rng_range,n,skip", [(2**32, 3000, 0), (2**32, 700, 1300), (2**32 + 1, 5000, 11), (3 * 2**32 - 1, 4000, 623),
+                                              (2**33, 2500, 1), (20000 * 300000, 3000, 0), (2**40 + 12345, 2000, 77)])
+def test_ranges_of_2_to_32_and_more_vs_oracle(rng_range, n, skip):
+    """RelMF draws cells from UniformGenerator(0, U*I) on long (cymf/relmf.pyx:128): at 2^32 libstdc++ takes one raw word,
+    above it a Lemire-drawn high part times 2^32 plus a raw word, the pair redrawn while it exceeds the range
+    (bits/uniform_int_dist.h:325-347; 2^32 + 1 rejects half of the pairs).  skip lands inside blocks and pairs."""
+    got = _lib.rng_fill_uniform(1234, rng_range, n, skip=skip)
+    assert np.array_equal(got, oracle.uniform_stream(1234, rng_range, n, skip=skip))
+    assert got.max() < rng_range and got.min() >= 0
+
+
 def test_range_limits_are_errors():
     with pytest.raises(_lib.CymfError):
-        _lib.rng_fill_uniform(1234, 2**32, 10)
+        _lib.rng_fill_uniform(1234, 2**62 + 1, 10)
     with pytest.raises(_lib.CymfError):
         _lib.rng_fill_uniform(1234, 0, 10)
     assert len(_lib.rng_fill_uniform(1234, 10, 0)) == 0
