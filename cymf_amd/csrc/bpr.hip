@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     using RowT = Row<float, R, PACKED>;
     constexpr int NS = opt_num_states(OPT);
     constexpr int NSA = NS ? NS : 1;
+    constexpr float SFILL = OPT == CYMF_OPT_ADAGRAD ? 1.0f : 0.0f;   // masked lanes of optimizer-state rows (rows.h: Row::load)
     static_assert(64 % PF == 0, "ring depth must divide the chunk");
     const int diag = xcd_stride >> 8;      // developer diagnostics (tools/sweep_step.py): bit0 no H[j] atomics, bit1 no W store, bit2 all H[j] atomic
     xcd_stride &= 255;
@@ -454,13 +455,13 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
         const int64_t ou = (int64_t)u * K;
         wq[p].load(d.W + ou, K, lane);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) swq[p][q].load(Ws[q] + ou, K, lane);
+        for (int q = 0; q < NS; ++q) swq[p][q].load(Ws[q] + ou, K, lane, SFILL);
     };
     auto issue_j = [&](int p, int32_t j) {
         const int64_t oj = (int64_t)(j < 0 ? 0 : (j & 0x3fffffff)) * K;
         jq[p].load(d.H + oj, K, lane);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) sjq[p][q].load(Hs[q] + oj, K, lane);
+        for (int q = 0; q < NS; ++q) sjq[p][q].load(Hs[q] + oj, K, lane, SFILL);
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p) issue_w(p, bcast_lane(u_c, p));
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
                         cur_item = item;
                         hi.load(d.H + (int64_t)item * K, K, lane);
 #pragma unroll
-                        for (int q = 0; q < NS; ++q) shi[q].load(Hs[q] + (int64_t)item * K, K, lane);
+                        for (int q = 0; q < NS; ++q) shi[q].load(Hs[q] + (int64_t)item * K, K, lane, SFILL);
                         settle<RowT, R>(hi);
                         hi0 = hi;
 #pragma unroll

@@ -19,7 +19,11 @@ struct Row {
 
     struct alignas(sizeof(T) * R) Vec { T x[R]; };
 
-    __device__ __forceinline__ void load(const T *__restrict__ base, int K, int lane) {
+    // `fill` is what the lanes past K hold (strided layout).  Parameter rows use 0: they then drop out of every dot
+    // product and gradient.  AdaGrad accumulator rows that stay in registers across several samples must use 1: a
+    // masked lane has g = 0 and acc = 0, and lr * 0 * rsqrt(0) = NaN would enter the row's masked lanes and, through the
+    // next sample's wave-wide dot product, everything (found by tests/test_gpu_bpr.py's boundary test at K = 8).
+    __device__ __forceinline__ void load(const T *__restrict__ base, int K, int lane, T fill = T(0)) {
         if constexpr (PACKED) {
             Vec t = *reinterpret_cast<const Vec *>(base + lane * R);
 #pragma unroll
@@ -28,7 +32,7 @@ struct Row {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 int k = lane + 64 * r;
-                v[r] = k < K ? base[k] : T(0);
+                v[r] = k < K ? base[k] : fill;
             }
         }
     }

@@ -603,6 +603,7 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
     constexpr int NS = opt_num_states(OPT);
     constexpr int NSA = NS ? NS : 1;
     constexpr int RING = 2 * PF;
+    constexpr float SFILL = OPT == CYMF_OPT_ADAGRAD ? 1.0f : 0.0f;   // masked lanes of optimizer-state rows (rows.h: Row::load)
     static_assert(64 % RING == 0, "ring must divide the chunk");
     const int lane = lane_id();
     const int K = d.K;
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
         RowT w, sw[NSA];
         w.load(d.W + u * K, K, lane);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) sw[q].load(Ws[q] + u * K, K, lane);
+        for (int q = 0; q < NS; ++q) sw[q].load(Ws[q] + u * K, K, lane, SFILL);
         auto load_meta = [&](int64_t c) -> int32_t {
             const int64_t my = s_begin + (c << 6) + lane;
             int32_t it = (c < c_end && my < s_end) ? items[my] : -1;
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
             const int64_t oi = (int64_t)(i < 0 ? 0 : i) * K;
             if (d.coherent) hq[e].load_coherent(d.H + oi, K, lane); else hq[e].load(d.H + oi, K, lane);
 #pragma unroll
-            for (int q = 0; q < NS; ++q) shq[e][q].load(Hs[q] + oi, K, lane);
+            for (int q = 0; q < NS; ++q) shq[e][q].load(Hs[q] + oi, K, lane, SFILL);
             xq[e] = xrow[i < 0 ? 0 : i];                            // wave-uniform addresses
             pq[e] = d.prop[i < 0 ? 0 : i];
         };

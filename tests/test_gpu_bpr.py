@@ -6,6 +6,7 @@ relative in the two norms of SURVEY.md 7 hard-3 for float32 device arithmetic; t
 device path is held to 1e-10."""
 import numpy as np
 import pytest
+from scipy import sparse
 
 import oracle
 from conftest import csr_from_golden, golden, rel_fro, rel_maxabs
@@ -273,7 +274,7 @@ def test_step_kernel_boundaries_every_slot_exactly_once(K, opt, item_aligned, mo
     users, pos, indptr, indices = _trainer_inputs(X)
     W0, H0 = oracle.reference_init(U, I, K)
     W0, H0 = W0.astype(np.float32).astype(np.float64), H0.astype(np.float32).astype(np.float64)   # what the device holds
-    lr = 1e-5
+    lr = 1e-6 if opt == "adam" else 1e-3   # Adam moves every entry by ~lr per touch whatever the gradient: keep that far below the entries
     monkeypatch.setenv("CYMF_BPR_MAX_WAVES", "5")
     monkeypatch.setenv("CYMF_BPR_ROWS_PER_INFLIGHT", "1")
     monkeypatch.setenv("CYMF_BPR_ADAPTIVE_RPI", "1")
@@ -305,22 +306,28 @@ def test_step_kernel_boundaries_every_slot_exactly_once(K, opt, item_aligned, mo
         # Exact for the user rows (one triplet each); item rows are touched repeatedly and only bounded here.
         step = (W - W0)[touchW == 1]
         assert (np.abs(step) <= lr * 1.02).all() and (np.abs(np.abs(step) - lr) <= 0.02 * lr).mean() > 0.99
-        assert (np.sign(step) == np.sign(dW[touchW == 1])).mean() > 0.99
+        # sign(g_w) = sign(H[i] - H[j]) at the time of the touch: the hot item's row drifts by up to 2.3 lr per touch under
+        # Adam, so only the users of the cold items (<= 3 touches each) are held to the sign of the INITIAL difference
+        cold = (touchW == 1) & (np.arange(U) >= 200)
+        assert (np.sign((W - W0)[cold]) == np.sign(dW[cold])).mean() > 0.97
         assert np.array_equal((W - W0)[touchW == 0], np.zeros_like(W0[touchW == 0]))
-        assert (np.abs(H - H0) <= touchH[:, None] * lr * 1.02).all() and np.abs(H - H0)[7].min() > 0
+        # repeated touches: the constant-correction Adam step is bounded by 2.3 lr (rows.h), not by lr
+        assert (np.abs(H - H0) <= touchH[:, None] * lr * 2.4).all() and np.abs(H - H0)[7].min() > 0
         assert np.array_equal((H - H0)[touchH == 0], np.zeros_like(H0[touchH == 0]))
         return
-    # Per row, relative to the row's largest predicted change: 0.1 % second-order (the hot row moves by 200 * lr / 2 of itself),
-    # float32 rounding of an update against its row value <= 0.6 % per touch and random, AdaGrad's 1/sqrt(acc) < 0.01 %.
-    # The hot row (200 touches) is therefore pinned to 0.31 %: ONE missing or doubled update of it is 0.5 %.
-    for got, pred, touches, strict in ((W - W0, dW, touchW, np.ones(U, dtype=bool)), (H - H0, dH, touchH, lossless)):
+    # Per row, relative to the row's largest predicted change.  Item rows: g = -/+ s w with w a user row at its ONLY touch
+    # (exactly W0[u]) and s = 1/2 - x/4, |x| < 1e-4: the prediction is exact to 1e-4 whatever the other rows do; float32
+    # rounding of an update against its row value is 1.2e-4 (lr / 2 = 5e-4 of the value per touch); AdaGrad's 1/sqrt(acc)
+    # stays within 0.1 % (acc <= 1 + 200 g^2, g ~ 3e-3).  The hot row's 200 updates add up like a random walk (about 14
+    # update sizes), so ONE missing or doubled update of it is ~7 % of the net change: 0.4 % pins every one of them.
+    # User rows: g = s (H[i] - H[j]) sees the hot row's random walk (~14 x lr / 2 = 0.7 % of an entry's size) -> 3 %.
+    for got, pred, touches, strict, tol in ((W - W0, dW, touchW, np.ones(U, dtype=bool), 0.03), (H - H0, dH, touchH, lossless, 0.004)):
         ref = np.abs(pred).max(axis=1)
         err = np.abs(got - pred).max(axis=1)
-        tol = 0.002 + 0.015 / np.sqrt(np.maximum(touches, 1))
         bad = strict & (err > tol * ref + 1e-12)
         assert not bad.any(), (np.flatnonzero(bad)[:5], (err / np.maximum(ref, 1e-30))[bad][:5], touches[bad][:5])
         assert np.array_equal(got[touches == 0], np.zeros_like(got[touches == 0]))
-        assert (np.abs(got) <= touches[:, None] * lr * 0.5 * 0.2 / K * 1.05 + 1e-12).all()   # |s| <= ~1/2, |row entries| <= 0.1/K (x2 for a difference)
+        assert (np.abs(got) <= touches[:, None] * lr * 0.5 * 0.2 / K * 1.3 + 1e-12).all()   # |s| <= ~1/2, |row entries| <= 0.1/K (x2 for a difference, + drift)
     assert touchH[7] >= 190 and lossless.sum() > I - 40
 
 

@@ -92,7 +92,7 @@ def test_evaluator_matches_restatement():
     wantw = _restated(Xte, Xtr, W, H, k=[5, 65, 100, 5000])
     for key in wantw:
         assert gotw[key] == pytest.approx(wantw[key], rel=1e-12), key
-    assert gotw["Recall@5"] == pytest.approx(want["Recall@5"], rel=1e-12) and gotw["Recall@5000"] > 0.99
+    assert gotw["Recall@5"] == pytest.approx(want["Recall@5"], rel=1e-12) and gotw["Recall@5000"] == pytest.approx((np.diff(Xte.indptr) > 0).mean(), rel=1e-12)   # every held-out item ranked; users without one count 0 (evaluator.pyx:134-136)
     gotwu = UnbiasedEvaluator(Xte, Xtr, k=[80]).evaluate(W, H)
     wantwu = _restated(Xte, Xtr, W, H, k=[80], unbiased=True)
     for key in wantwu:
