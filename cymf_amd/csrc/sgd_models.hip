@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include "relmf_tiles.h"
 #include "store.h"
 
 namespace cymf {
@@ -892,6 +893,11 @@ struct cymf_relmf {
     // step path (f32 throughput, K <= 128): the cells of epoch e+1 are generated and bucketed by user on
     // side_stream while relmf_step_kernel works through epoch e; buffers double-buffered by epoch parity
     bool step_path = false;
+    // tile path (relmf_tiles.hip): the default lock-free mode on one GPU -- B x B stratified tiles, item rows in LDS, no
+    // atomics on HBM; the user-bucketed step path above remains for the multi-GPU exchange (and CYMF_RELMF_NO_TILES=1)
+    bool tile_ok = false;
+    RelTilePlan plan;
+    RelTileBufs tb;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_bucketed[2] = {nullptr, nullptr}, ev_step_done[2] = {nullptr, nullptr};
     DevBuf<int64_t> d_uoff[2];
@@ -946,10 +952,28 @@ static int relmf_prepare(cymf_relmf *h, int64_t g_want) {
     return 0;
 }
 
+// tile path: cells of epoch g generated on the side stream and grouped by tile into the buffers of parity g & 1
+static int relmf_prepare_tiles(cymf_relmf *h, int64_t g_want) {
+    const int64_t N = (int64_t)h->U * h->I;
+    while (h->epochs_prepared <= g_want) {
+        const int64_t g = h->epochs_prepared;
+        const int b = (int)(g & 1);
+        hipStream_t ss = h->side_stream;
+        CYMF_TRY(h->d_cells.alloc((size_t)N));
+        if (g >= 2) CYMF_HIP(hipStreamWaitEvent(ss, h->ev_step_done[b], 0));   // buffers b were read by the tile kernels of epoch g-2
+        CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, ss));
+        CYMF_TRY(relmf_tile_bucket(h->plan, h->d_cells.p, h->tb, b, ss));
+        CYMF_HIP(hipEventRecord(h->ev_bucketed[b], ss));
+        h->epochs_prepared++;
+    }
+    return 0;
+}
+
 template <typename T>
 static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
     const int64_t N = (int64_t)h->U * h->I;   // relmf.pyx:120: one epoch = U*I draws with replacement
-    const bool stepped = h->mode == CYMF_MODE_THROUGHPUT && h->step_path && sizeof(T) == 4;
+    const bool tiled = h->mode == CYMF_MODE_THROUGHPUT && h->tile_ok && !h->comm && sizeof(T) == 4;
+    const bool stepped = tiled || (h->mode == CYMF_MODE_THROUGHPUT && h->step_path && sizeof(T) == 4);
     if (!stepped) {
         CYMF_TRY(h->d_cells.alloc((size_t)N));
         CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, h->stream));
@@ -959,7 +983,24 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
     d.X = st.X.p; d.prop = st.prop.p; d.K = h->K; d.I = h->I; d.wd = (T)h->wd; d.clip = (T)h->clip;
     d.opt = make_opt_params<T>(h->lr);
     CYMF_TRY(h->d_loss.zero(h->stream));
-    if (h->mode == CYMF_MODE_THROUGHPUT && h->step_path) {
+    if (tiled) {
+        if constexpr (sizeof(T) == 4) {
+            const int64_t e = h->epoch_cursor;
+            const int b = (int)(e & 1);
+            CYMF_TRY(relmf_prepare_tiles(h, e));
+            CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_bucketed[b], 0));
+            CYMF_TRY(relmf_prepare_tiles(h, e + 1));   // next epoch's cells and tiles, concurrently with this epoch's sub-steps
+            RelTileParams tp;
+            tp.W = st.W.p; tp.H = st.H.p; tp.W0 = st.W0.p; tp.W1 = st.W1.p; tp.H0 = st.H0.p; tp.H1 = st.H1.p;
+            tp.X = st.X.p; tp.prop = st.prop.p; tp.wd = (float)h->wd; tp.clip = (float)h->clip;
+            tp.opt = make_opt_params<float>(h->lr);
+            CYMF_TRY(h->d_err.alloc(1));
+            CYMF_TRY(h->d_err.zero(h->stream));
+            CYMF_TRY(relmf_tile_epoch(h->plan, tp, h->tb, b, e, h->d_loss.p, h->d_err.p, h->stream));
+            CYMF_HIP(hipEventRecord(h->ev_step_done[b], h->stream));
+            h->epoch_cursor++;
+        }
+    } else if (h->mode == CYMF_MODE_THROUGHPUT && h->step_path) {
         if constexpr (sizeof(T) == 4) {
             const int64_t e = h->epoch_cursor;
             const int b = (int)(e & 1);
@@ -1049,7 +1090,7 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
     if (stepped) CYMF_HIP(hipMemcpyAsync(&err, h->d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     CYMF_HIP(hipMemcpyAsync(&loss, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
-    if (err) return fail(CYMF_ERR_HIP, "relmf: the per-epoch bucketing produced an item index outside [0, I)");
+    if (err) return fail(CYMF_ERR_HIP, "relmf: the per-epoch bucketing produced an index outside its block");
     if (loss_out) *loss_out = loss;
     return 0;
 }
@@ -1075,7 +1116,9 @@ extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t
     }
     int rc = h->d_loss.alloc(1);
     h->step_path = mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && K <= 128 && !(getenv("CYMF_RELMF_NO_STEP") && getenv("CYMF_RELMF_NO_STEP")[0] == '1');
-    if (!rc && h->step_path) {
+    h->tile_ok = mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && relmf_tile_plan(U, I, K, optimizer, &h->plan) &&
+                 !(getenv("CYMF_RELMF_NO_TILES") && getenv("CYMF_RELMF_NO_TILES")[0] == '1');
+    if (!rc && (h->step_path || h->tile_ok)) {
         hipError_t e2 = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
         for (int b = 0; b < 2 && e2 == hipSuccess; ++b) {
             e2 = hipEventCreateWithFlags(&h->ev_bucketed[b], hipEventDisableTiming);
@@ -1085,7 +1128,7 @@ extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t
     }
     // relmf.pyx:128; >= 2M cells per epoch: chunked jump-ahead generator (rng.hip), else the one-workgroup walker.
     // The generator lives on the stream that consumes it: the side stream on the step path.
-    if (!rc) rc = h->rng.init(seed, (uint64_t)U * (uint64_t)I, h->step_path ? h->side_stream : h->stream,
+    if (!rc) rc = h->rng.init(seed, (uint64_t)U * (uint64_t)I, (h->step_path || h->tile_ok) ? h->side_stream : h->stream,
                               /*parallel=*/(int64_t)U * I >= (int64_t)2 << 20);
     if (rc) { (void)cymf_relmf_destroy(h); return rc; }
     *out = h;

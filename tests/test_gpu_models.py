@@ -52,9 +52,11 @@ def test_relmf_larger_vs_oracle_and_sparse_input():
 
 @pytest.mark.parametrize("optimizer,lr", [("sgd", 0.02), ("adagrad", 0.05), ("adam", 0.002)])
 def test_relmf_step_path_tracks_the_sequential_oracle(optimizer, lr):
-    """Throughput mode at a size that takes the chunked index stream (>= 2M cells) and the per-epoch device
-    bucketing (relmf_step_kernel): the same cells in another order, lock-free -- epoch losses and factor
-    norms follow the sequential oracle; the old one-sample-per-wave kernel (CYMF_RELMF_NO_STEP) agrees too."""
+    """Throughput mode at a size that takes the chunked index stream (>= 2M cells) and the per-epoch device bucketing:
+    the same cells in another order, lock-free -- epoch losses and factor norms follow the sequential oracle.  Default:
+    the stratified tile schedule (relmf_tiles.hip: B x B tiles, item rows in LDS, no atomics on HBM, every update
+    applied exactly once); CYMF_RELMF_NO_TILES=1: the user-bucketed step kernel with float atomics that the multi-GPU
+    exchange still uses."""
     rs = np.random.RandomState(3)
     U, I, K = 1500, 1400, 32
     Xd = (rs.rand(U, I) < 0.03).astype(np.float64)
@@ -66,10 +68,53 @@ def test_relmf_step_path_tracks_the_sequential_oracle(optimizer, lr):
     m.fit(Xd, num_epochs=2, num_threads=0)
     assert np.isfinite(m.W).all() and np.isfinite(m.H).all()
     np.testing.assert_allclose(m.losses, want, rtol=3e-2)
-    # Adam's normalised steps make the lock-free item side run ahead of the sequential one (every concurrent holder
-    # of an item row adds a full-size step): the objective agrees, the norm of H ends ~35 % larger at this rate
+    assert abs(np.linalg.norm(m.W) / np.linalg.norm(W) - 1) < 0.15 and abs(np.linalg.norm(m.H) / np.linalg.norm(H) - 1) < 0.15
+
+
+@pytest.mark.parametrize("optimizer,lr", [("sgd", 0.02), ("adam", 0.002)])
+def test_relmf_user_bucketed_step_kernel_still_tracks_the_oracle(optimizer, lr, monkeypatch):
+    monkeypatch.setenv("CYMF_RELMF_NO_TILES", "1")
+    rs = np.random.RandomState(3)
+    U, I, K = 1500, 1400, 32
+    Xd = (rs.rand(U, I) < 0.03).astype(np.float64)
+    prop = np.maximum(Xd.mean(axis=0) / Xd.mean(axis=0).max(), 1e-5) ** 0.5
+    W, H = oracle.reference_init(U, I, K)
+    om = oracle.RelMf(W, H, optimizer, lr, 0.01, 0.1)
+    want = [om.epoch(Xd, prop) for _ in range(2)]
+    m = RelMF(K, 0.1, lr, optimizer, 0.01)
+    m.fit(Xd, num_epochs=2, num_threads=0)
+    np.testing.assert_allclose(m.losses, want, rtol=3e-2)
+    # Adam's normalised steps make the atomics-based item side run ahead of the sequential one: every concurrent holder of
+    # an item row adds a full-size step
     tol_h = 0.5 if optimizer == "adam" else 0.15
     assert abs(np.linalg.norm(m.W) / np.linalg.norm(W) - 1) < 0.15 and abs(np.linalg.norm(m.H) / np.linalg.norm(H) - 1) < tol_h
+
+
+@pytest.mark.parametrize("U,I,K,optimizer", [(300, 70, 20, "sgd"), (64, 900, 100, "adagrad"), (2000, 33, 130, "adam"), (90, 5000, 8, "sgd"),
+                                              (40, 50, 256, "sgd")])
+def test_relmf_tile_schedule_shapes_every_draw_applied_once(U, I, K, optimizer):
+    """The tile schedule on shapes that bend its plan: fewer users than workgroups, a single item per block, K off the
+    64-lane rows, blocks whose last tile is short.  With a tiny learning rate the factors barely move, so the epoch loss
+    is the sum over the drawn cells of the loss at the initial factors: it must equal the sequential oracle's (every draw
+    of the stream applied exactly once, none dropped or doubled), and the factors must move the same distance."""
+    rs = np.random.RandomState(K)
+    Xd = (rs.rand(U, I) < 0.1).astype(np.float64)
+    prop = np.maximum(Xd.mean(axis=0) / max(Xd.mean(axis=0).max(), 1e-9), 1e-5) ** 0.5
+    lr = 1e-5
+    W, H = oracle.reference_init(U, I, K)
+    W0, H0 = W.copy(), H.copy()
+    om = oracle.RelMf(W, H, optimizer, lr, 0.01, 0.1)
+    want = om.epoch(Xd, prop)
+    m = RelMF(K, 0.1, lr, optimizer, 0.01)
+    m.fit(Xd, num_epochs=1, num_threads=0)
+    assert m.losses[0] == pytest.approx(want, rel=5e-6)   # one tile of 250 x 250 dropped or doubled would be 1.6e-5
+    # sgd: the movement is the sum of the gradients at (almost) the initial point, whatever the order; float32 rounds every
+    # one of a row's hundreds or thousands of tiny updates against the row's value (the atomics-based step kernel shows
+    # the same 2 % / 11 % on the 90 x 5000 case)
+    if optimizer == "sgd":
+        dW, dH = m.W - W0.astype(np.float32), m.H - H0.astype(np.float32)
+        assert np.linalg.norm(dW - (W - W0)) <= 0.15 * np.linalg.norm(W - W0)
+        assert np.linalg.norm(dH - (H - H0)) <= 0.15 * np.linalg.norm(H - H0)
 
 
 # ------------------------------------------------------------------ GloVe

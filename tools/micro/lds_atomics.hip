@@ -24,6 +24,16 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, int stride_rows
         else if (MODE == 4) atomicAdd(&ul[a], 1u);                       // ds_add_u32
         else if (MODE == 5) atomicAdd(&ul[(row & 127) * 64 + (lane >> 3)], 1u);   // 8 lanes per address
         else if (MODE == 6) { float v = lds[a]; lds[a] = v + 1.0f; }     // plain read-modify-write
+        else if (MODE == 7) {                                            // float add by compare-and-swap (ds_cmpst_rtn_b32), one attempt + retry loop
+            unsigned int old = ul[a];
+            while (true) {
+                const unsigned int want = __float_as_uint(__uint_as_float(old) + 1.0f);
+                const unsigned int seen = atomicCAS(&ul[a], old, want);
+                if (seen == old) break;
+                old = seen;
+            }
+        }
+        else if (MODE == 8) acc += (float)atomicAdd(&ul[a], 1u);         // ds_add_rtn_u32
         row += stride_rows;
     }
     const long long t1 = clock64();
@@ -34,10 +44,10 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, int stride_rows
 int main() {
     float *d;
     hipMalloc(&d, 4096 * sizeof(float));
-    const char *names[] = {"ds_read_b32", "ds_write_b32", "ds_add_f32", "ds_add_rtn_f32", "ds_add_u32", "ds_add_u32 8 lanes/addr", "read+write RMW"};
+    const char *names[] = {"ds_read_b32", "ds_write_b32", "ds_add_f32", "ds_add_rtn_f32", "ds_add_u32", "ds_add_u32 8 lanes/addr", "read+write RMW", "float add via ds_cmpst_rtn", "ds_add_rtn_u32"};
     for (int threads : {64, 256, 1024}) {
-        for (int mode = 0; mode < 7; ++mode) {
-            for (int blocks : {1, 256}) {
+        for (int mode = 0; mode < 9; ++mode) {
+            for (int blocks : {256}) {
                 hipMemset(d, 0, 4096 * sizeof(float));
                 const int iters = 4096, nw = threads / 64;
                 switch (mode) {
@@ -47,6 +57,8 @@ int main() {
                 case 3: hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(threads), 32768, 0, d, iters, nw); break;
                 case 4: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(threads), 32768, 0, d, iters, nw); break;
                 case 5: hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(threads), 32768, 0, d, iters, nw); break;
+                case 7: hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(threads), 32768, 0, d, iters, nw); break;
+                case 8: hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(threads), 32768, 0, d, iters, nw); break;
                 default: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(threads), 32768, 0, d, iters, nw); break;
                 }
                 hipDeviceSynchronize();
