@@ -131,10 +131,7 @@ def main():
         mine = np.nonzero((all_users >= lo) & (all_users < hi))[0]       # global positions of my triplets
         users, positives, gpos = np.asarray(all_users[mine]), np.asarray(data["positives"][mine]), mine.astype(np.int64)
         # the membership structure (cymf/bpr.pyx:146-147) of this rank's users only: other users' rows are empty
-        ip = np.zeros(U + 1, dtype=np.int64)
-        ip[lo:hi + 1] = indptr[lo:hi + 1] - indptr[lo]
-        ip[hi + 1:] = ip[hi]
-        csr_indptr, csr_indices = ip.astype(np.int32), np.ascontiguousarray(cols[indptr[lo]:indptr[hi]])
+        csr_indptr, csr_indices = dist.shard_pattern(indptr, cols, (lo, hi))
     else:
         users, positives, gpos = data["users"], data["positives"], None
         csr_indptr, csr_indices = indptr.astype(np.int32), cols

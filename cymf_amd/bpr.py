@@ -55,8 +55,9 @@ class BPR(object):
 
         global_pos, n_global = None, len(users)
         if shard is not None:   # user-sharded: keep this rank's users, remember global positions
-            from .dist import shard_triplets
+            from .dist import shard_pattern, shard_triplets
             users, positives, global_pos = shard_triplets(users, positives, shard)
+            indptr, indices = shard_pattern(indptr, indices, shard)
 
         trainer = BprTrainer(U, I, self.num_components, self.optimizer, self.learning_rate, self.weight_decay,
                              dtype=dtype, mode=mode, device=device, steps_per_epoch=steps_per_epoch, comm=comm)

@@ -783,6 +783,7 @@ struct cymf_bpr {
 namespace cymf {
 int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s);   // comm.hip
 int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, hipStream_t s);
+int64_t comm_padded_count(cymf_comm *c, int64_t n);
 int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_t row_bytes, hipStream_t s);
 int comm_rank(cymf_comm *c);
 int comm_world(cymf_comm *c);
@@ -1563,7 +1564,12 @@ extern "C" int cymf_bpr_upload(cymf_bpr *h, const double *W, const double *H) {
         if (h->comm_stream) CYMF_HIP(hipStreamSynchronize(h->comm_stream));   // (a re-upload drops an exchange in flight)
         CYMF_TRY(h->d_snap.alloc(n));
         if (h->overlap_exchange) {
-            for (int b = 0; b < 2; ++b) { CYMF_TRY(h->d_local[b].alloc(n)); CYMF_TRY(h->d_glob[b].alloc(n)); }
+            // the exchange is a reduce-scatter + all-gather over equal shards: buffers padded to a multiple of the world, padding zero
+            const size_t n_pad = (size_t)comm_padded_count(h->comm, (int64_t)n);
+            for (int b = 0; b < 2; ++b) {
+                CYMF_TRY(h->d_local[b].alloc(n_pad)); CYMF_TRY(h->d_glob[b].alloc(n_pad));
+                CYMF_TRY(h->d_local[b].zero(h->stream)); CYMF_TRY(h->d_glob[b].zero(h->stream));
+            }
             CYMF_TRY(h->d_base.alloc(n));
             CYMF_HIP(hipMemcpyAsync(h->d_base.p, h->f32.H.p, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
             h->exch_pending = false;

@@ -32,13 +32,26 @@ struct cymf_comm {
     int rank = 0, world = 1, device = 0;
     LocalGroup *grp = nullptr;
     long long gen = 0;                   // collectives issued by this rank (all ranks issue the same sequence)
+    bool failed = false;                 // an RCCL call on this communicator returned an error: destroy aborts it
 };
 
+// RCCL calls that do not involve a communicator
 #define CYMF_NCCL(expr)                                                                         \
     do {                                                                                        \
         ncclResult_t r__ = (expr);                                                              \
         if (r__ != ncclSuccess)                                                                 \
             return ::cymf::fail(CYMF_ERR_RCCL, "%s failed: %s", #expr, ncclGetErrorString(r__)); \
+    } while (0)
+
+// RCCL calls on communicator c: a failure marks the communicator (cymf_comm_destroy then calls ncclCommAbort: an
+// ncclCommDestroy of a communicator with a failed or half-issued collective can block for ever waiting for its peers)
+#define CYMF_NCCL_C(c, expr)                                                                    \
+    do {                                                                                        \
+        ncclResult_t r__ = (expr);                                                              \
+        if (r__ != ncclSuccess) {                                                               \
+            (c)->failed = true;                                                                 \
+            return ::cymf::fail(CYMF_ERR_RCCL, "%s failed on rank %d of %d: %s", #expr, (c)->rank, (c)->world, ncclGetErrorString(r__)); \
+        }                                                                                       \
     } while (0)
 
 
@@ -109,16 +122,45 @@ int local_allreduce(cymf_comm *c, const float *d_in, float *d_out, int64_t n, in
 
 namespace cymf {
 
-int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s) {
-    if (c->grp) return local_allreduce(c, d_buf, d_buf, n, 0, s);
-    CYMF_NCCL(ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
+// Errors of enqueued collectives surface asynchronously (a peer died, a link went down): asked for after every call
+// that enqueues work, so that the NEXT entry point fails with the reason instead of hanging in a stream wait.
+static int comm_check_async(cymf_comm *c, const char *what) {
+    ncclResult_t aerr = ncclSuccess;
+    ncclResult_t r = ncclCommGetAsyncError(c->comm, &aerr);
+    if (r != ncclSuccess || (aerr != ncclSuccess && aerr != ncclInProgress)) {
+        c->failed = true;
+        return fail(CYMF_ERR_RCCL, "%s: asynchronous RCCL error on rank %d of %d: %s", what, c->rank, c->world,
+                    ncclGetErrorString(r != ncclSuccess ? r : aerr));
+    }
     return 0;
 }
 
+int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s) {
+    if (c->grp) return local_allreduce(c, d_buf, d_buf, n, 0, s);
+    if (c->failed) return fail(CYMF_ERR_RCCL, "communicator of rank %d is in a failed state", c->rank);
+    CYMF_NCCL_C(c, ncclAllReduce(d_buf, d_buf, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
+    return comm_check_async(c, "ncclAllReduce");
+}
+
+// Elements a buffer must hold for comm_allreduce_sum_f32_to: n rounded up to a multiple of the world size (the
+// reduce-scatter / all-gather pair works on equal shards; the caller keeps the padding zero).
+int64_t comm_padded_count(cymf_comm *c, int64_t n) {
+    const int64_t w = c ? c->world : 1;
+    return (n + w - 1) / w * w;
+}
+
+// d_out = sum over the ranks of d_in, as reduce-scatter + all-gather: each rank reduces one shard of
+// 1 / world of the table and the shards are gathered in place -- the two halves of a ring all-reduce, issued as such so
+// that the per-link traffic over xGMI is (world - 1) / world of the table each way and a shard is reduced once.  Two
+// calls in stream order (not one group: the all-gather reads what the reduce-scatter wrote, and a group promises no
+// order between its members).  Both buffers hold comm_padded_count(n) floats.
 int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, hipStream_t s) {
     if (c->grp) return local_allreduce(c, d_in, d_out, n, 0, s);
-    CYMF_NCCL(ncclAllReduce(d_in, d_out, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
-    return 0;
+    if (c->failed) return fail(CYMF_ERR_RCCL, "communicator of rank %d is in a failed state", c->rank);
+    const int64_t shard = comm_padded_count(c, n) / c->world;
+    CYMF_NCCL_C(c, ncclReduceScatter(d_in, d_out + (size_t)c->rank * shard, (size_t)shard, ncclFloat32, ncclSum, c->comm, s));
+    CYMF_NCCL_C(c, ncclAllGather(d_out + (size_t)c->rank * shard, d_out, (size_t)shard, ncclFloat32, c->comm, s));
+    return comm_check_async(c, "reduce-scatter + all-gather");
 }
 
 int comm_world(cymf_comm *c) { return c ? c->world : 1; }
@@ -148,7 +190,8 @@ int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_
                 }
             });
     }
-    CYMF_NCCL(ncclGroupStart());
+    if (c->failed) return fail(CYMF_ERR_RCCL, "communicator of rank %d is in a failed state", c->rank);
+    CYMF_NCCL_C(c, ncclGroupStart());
     for (int r = 0; r < c->world; ++r) {
         const int64_t n = (row_bounds[r + 1] - row_bounds[r]) * row_bytes;
         if (n <= 0) continue;
@@ -156,11 +199,12 @@ int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_
         ncclResult_t rc = ncclBroadcast(p, p, (size_t)n, ncclChar, r, c->comm, s);
         if (rc != ncclSuccess) {
             (void)ncclGroupEnd();
-            return ::cymf::fail(CYMF_ERR_RCCL, "ncclBroadcast failed: %s", ncclGetErrorString(rc));
+            c->failed = true;
+            return ::cymf::fail(CYMF_ERR_RCCL, "ncclBroadcast failed on rank %d of %d: %s", c->rank, c->world, ncclGetErrorString(rc));
         }
     }
-    CYMF_NCCL(ncclGroupEnd());
-    return 0;
+    CYMF_NCCL_C(c, ncclGroupEnd());
+    return comm_check_async(c, "grouped broadcasts");
 }
 
 }  // namespace cymf
@@ -214,7 +258,13 @@ extern "C" int cymf_comm_create_local_group(cymf_comm **out, int world, int devi
 extern "C" int cymf_comm_destroy(cymf_comm *c) {
     if (!c) return 0;
     if (!cymf::runtime_alive(c->device)) return 0;   // process exit / runtime already torn down: leak quietly
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->comm) {
+        // a communicator on which a call failed (or whose peers may be gone) is aborted: ncclCommDestroy would wait for
+        // collectives that can never complete
+        ncclResult_t aerr = ncclSuccess;
+        if (!c->failed && ncclCommGetAsyncError(c->comm, &aerr) == ncclSuccess && aerr == ncclSuccess) (void)ncclCommDestroy(c->comm);
+        else (void)ncclCommAbort(c->comm);
+    }
     if (c->grp && --c->grp->refs == 0) {   // (handles of a local group are destroyed from one thread, after the ranks have joined)
         (void)hipDeviceSynchronize();
         (void)hipFree(c->grp->slots);
@@ -240,8 +290,10 @@ extern "C" int cymf_comm_allreduce_f32(cymf_comm *c, float *host_inout, int64_t 
         (void)hipStreamDestroy(s);
         return rc;
     }
+    if (c->failed) return fail(CYMF_ERR_RCCL, "communicator of rank %d is in a failed state", c->rank);
     CYMF_HIP(hipDeviceSynchronize());
-    CYMF_NCCL(ncclAllReduce(d.p, d.p, (size_t)n, ncclFloat32, op == 1 ? ncclMax : ncclSum, c->comm, nullptr));
+    CYMF_NCCL_C(c, ncclAllReduce(d.p, d.p, (size_t)n, ncclFloat32, op == 1 ? ncclMax : ncclSum, c->comm, nullptr));
+    CYMF_TRY(comm_check_async(c, "ncclAllReduce"));
     CYMF_HIP(hipMemcpy(host_inout, d.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }

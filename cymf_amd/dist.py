@@ -39,6 +39,18 @@ def shard_triplets(users, positives, shard):
     return users[keep], np.asarray(positives)[keep], keep.astype(np.int64)
 
 
+def shard_pattern(indptr, indices, shard):
+    """CSR pattern of X restricted to this rank's users: the rows of the other users are empty.  The membership
+    structure (cymf/bpr.pyx:146-147) is only ever asked about a rank's own users, so its device form (a hash set of
+    (user, item) pairs, 2 x 8 bytes per interaction) shrinks by the world size."""
+    lo, hi = shard
+    indptr = np.asarray(indptr, dtype=np.int64)
+    out = np.zeros(len(indptr), dtype=np.int64)
+    out[lo:hi + 1] = indptr[lo:hi + 1] - indptr[lo]
+    out[hi + 1:] = out[hi]
+    return out.astype(np.int32), np.ascontiguousarray(np.asarray(indices)[indptr[lo]:indptr[hi]], dtype=np.int32)
+
+
 def step_of(global_pos, steps_per_epoch, n_global):
     """Step (window of the global order) a triplet belongs to; mirrors build_throughput_layout in csrc/bpr.hip."""
     return (np.asarray(global_pos, dtype=np.int64) * int(steps_per_epoch)) // max(int(n_global), 1)
