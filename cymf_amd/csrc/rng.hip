@@ -503,7 +503,7 @@ int DeviceRng::generate_parallel(int64_t n_total, int64_t n_skip, uint32_t *d_ou
     const int64_t need_raw = n_total + (int64_t)((double)n_total * p_rej * 1.5) + 4096;
     const int64_t n_chunks = ((int64_t)skip0 + need_raw + J - 1) / J;
     CYMF_TRY(ensure_states(c0 + n_chunks - 1, s));
-    CYMF_TRY(tmp_.alloc((size_t)n_chunks * (size_t)J));
+    CYMF_TRY(tmp_.reserve((size_t)n_chunks * (size_t)J));   // kept while large enough: the chunk count moves by one between epochs, and a hipFree is a device-wide sync
     if (n_chunks > pend_.cap_chunks) {
         if (pend_.h_counts) (void)hipHostFree(pend_.h_counts);
         if (pend_.h_rej) (void)hipHostFree(pend_.h_rej);

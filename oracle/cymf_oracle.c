@@ -9,7 +9,7 @@
  *
  * Pinning: the reference's own tests hold no vector for this path, so
  * the pin is the reference itself, compiled in the build container by oracle/build_ref.py
- * (oracle/_ref/) and compared bit-for-bit in tests/test_oracle_vs_reference.py, plus the
+ * (into a directory outside this repository) and compared bit-for-bit in tests/test_oracle_vs_reference.py, plus the
  * golden fixtures under tests/golden/ that tests/golden/make_golden.py generated from it.
  * WMF is the exception: the reference's wmf/linalg modules are unbuildable here (cblas.h),
  * so orc_wmf_* is "parity unpinned" by the reference and cross-checked against numpy's

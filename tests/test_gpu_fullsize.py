@@ -74,6 +74,119 @@ def test_c3_bpr_full_size_properties():
     assert np.abs(H).max() < 10.0
 
 
+def _c3_with_holdout():
+    """C3 with 2 % of the interactions of the first 100 000 users held out (a fixed pseudo-random subset)."""
+    from scipy import sparse
+    U, I, nnz, K, seed = synthetic.CONFIGS["C3"]
+    rows, cols, indptr = synthetic.implicit_matrix_large(U, I, nnz, seed)
+    n_eval_users = 100_000
+    n_head = int(indptr[n_eval_users])
+    held = np.zeros(len(rows), dtype=bool)
+    held[:n_head] = np.random.RandomState(77).rand(n_head) < 0.02
+    keep = ~held
+    tr_rows, tr_cols = rows[keep], cols[keep]
+    tr_indptr = np.zeros(U + 1, dtype=np.int64)
+    tr_indptr[1:] = np.cumsum(np.bincount(tr_rows, minlength=U))
+    Xte = sparse.csr_matrix((np.ones(int(held.sum())), (rows[held], cols[held])), shape=(n_eval_users, I))
+    Xtr_head = sparse.csr_matrix((np.ones(int(tr_indptr[n_eval_users])), tr_cols[:tr_indptr[n_eval_users]], tr_indptr[:n_eval_users + 1]),
+                                 shape=(n_eval_users, I))
+    perm = np.random.default_rng(4321).permutation(len(tr_rows))
+    rs = np.random.RandomState(4321)
+    W0 = rs.uniform(-0.1, 0.1, size=(U, K)) / K
+    H0 = rs.uniform(-0.1, 0.1, size=(I, K)) / K
+    return dict(U=U, I=I, K=K, users=tr_rows[perm], pos=tr_cols[perm], indptr=tr_indptr.astype(np.int32), cols=tr_cols,
+                W0=W0, H0=H0, Xte=Xte, Xtr_head=Xtr_head, n_eval_users=n_eval_users)
+
+
+def test_c3_lock_free_quality_at_the_benchmarked_wave_count(monkeypatch):
+    """The evidence behind the bench line: at C3's full size the run with the benchmarked number of wavefronts (up to 3 072,
+    twelve per CU, all eight XCDs) must learn like a run of the same item-bucketed order with 256 wavefronts -- epoch losses
+    within 2 %, held-out Recall@5 (device evaluator, 100 sampled negatives, cymf/evaluator.pyx:57-139) within 0.01."""
+    from cymf_amd import Evaluator
+    d = _c3_with_holdout()
+    ev = Evaluator(d["Xte"], d["Xtr_head"])
+    out = {}
+    for waves in ("3072", "256"):
+        monkeypatch.setenv("CYMF_BPR_MAX_WAVES", waves)
+        t = BprTrainer(d["U"], d["I"], d["K"], "sgd", 0.05, 0.01, mode="throughput", steps_per_epoch=25)
+        t.set_data(d["users"], d["pos"], d["indptr"], d["cols"])
+        t.upload(d["W0"], d["H0"])
+        losses = t.epochs(3)
+        W, H = np.empty_like(d["W0"]), np.empty_like(d["H0"])
+        t.download(W, H)
+        t.close()
+        out[waves] = (losses, ev.evaluate(W[:d["n_eval_users"]], H)["Recall@5"], np.linalg.norm(H))
+    ev.close()
+    (la, ra, na), (lb, rb, nb) = out["3072"], out["256"]
+    assert lb[2] < 0.75 * lb[0] and rb > 0.15                       # it does learn: far above the 0.05 of a random ranking
+    np.testing.assert_allclose(la, lb, rtol=0.02)
+    assert abs(ra - rb) < 0.01 and abs(na / nb - 1) < 0.05
+
+
+def test_c3_eight_virtual_ranks_track_the_single_rank():
+    """The multi-GPU schedule at the benchmarked shape (1M x 100k, 100M interactions, K=128, not a scaled-down problem):
+    eight ranks as eight host threads on one device (local-group communicator), users sharded by nnz, 3 steps per epoch
+    (= 25 / 8), damped item-delta sums exchanged under the next step.  Synchronous mini-batches of 33 M triplets on the
+    item table are behind the single rank's 4 M-triplet steps early on (measured after three epochs: loss 0.315 against
+    0.303, +3.9 %, the gap shrinking from +24 % after the first; the damped sums let the popular items' rows grow more slowly:
+    norm of H 0.76 of the single rank's) and converge towards it -- held-out Recall@5 is already the same, 0.4379 against 0.4383; the bar here: loss within 6 %, held-out Recall@5 within
+    0.03, norm of H within 30 %, item replicas identical on all ranks."""
+    import threading
+    from cymf_amd import Evaluator, dist
+    d = _c3_with_holdout()
+    U, I, K = d["U"], d["I"], d["K"]
+    world, S, epochs = 8, 3, 3
+    one = BprTrainer(U, I, K, "sgd", 0.05, 0.01, mode="throughput", steps_per_epoch=25)
+    one.set_data(d["users"], d["pos"], d["indptr"], d["cols"])
+    one.upload(d["W0"], d["H0"])
+    loss1 = one.epochs(epochs)
+    W1, H1 = np.empty_like(d["W0"]), np.empty_like(d["H0"])
+    one.download(W1, H1)
+    one.close()
+    comms = dist.Comm.local_group(world, I * K + 64)
+    shards = dist.user_shards(d["indptr"], world)
+    res, err = [None] * world, []
+
+    def work(r):
+        try:
+            u, p, gpos = dist.shard_triplets(d["users"], d["pos"], shards[r])
+            ip, ix = dist.shard_pattern(d["indptr"], d["cols"], shards[r])
+            t = BprTrainer(U, I, K, "sgd", 0.05, 0.01, mode="throughput", steps_per_epoch=S, comm=comms[r])
+            t.set_data(u, p, ip, ix, gpos, len(d["users"]))
+            t.upload(d["W0"], d["H0"])
+            losses = t.epochs(epochs) * len(u)              # back to sums: the ranks hold different numbers of triplets
+            W, H = np.empty_like(d["W0"]), np.empty_like(d["H0"])
+            t.download(W, H)
+            t.close()
+            lo, hi = shards[r]
+            res[r] = (losses, W[lo:hi].copy(), H)
+        except BaseException as e:   # noqa: BLE001 -- reported to the main thread
+            err.append((r, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not err, err
+    for c in comms:
+        c.close()
+    job_loss = sum(r[0] for r in res) / len(d["users"])
+    H8 = res[0][2]
+    assert all(np.array_equal(r[2], H8) for r in res)
+    W8 = np.concatenate([r[1] for r in res])
+    np.testing.assert_allclose(job_loss[-1], loss1[-1], rtol=0.06)
+    assert job_loss[-1] < job_loss[0] * 0.75
+    print("8 virtual ranks vs 1: loss", job_loss, loss1, "|H|", np.linalg.norm(H8) / np.linalg.norm(H1))
+    assert abs(np.linalg.norm(H8) / np.linalg.norm(H1) - 1) < 0.30
+    ev = Evaluator(d["Xte"], d["Xtr_head"])
+    n = d["n_eval_users"]
+    r1, r8 = ev.evaluate(W1[:n], H1)["Recall@5"], ev.evaluate(W8[:n], H8)["Recall@5"]
+    ev.close()
+    print("Recall@5 single", r1, "eight ranks", r8)
+    assert abs(r1 - r8) < 0.03 and r8 > 0.15
+
+
 def test_c4_wmf_full_size_normal_equations():
     U, I, nnz, K, seed = synthetic.CONFIGS["C4"]
     rows, cols, indptr = synthetic.implicit_matrix_large(U, I, nnz, seed)
