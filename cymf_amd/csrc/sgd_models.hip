@@ -55,8 +55,9 @@ struct RelDev {
 };
 
 // One draw: cell index -> (u, i) = (cell / I, cell % I)  (relmf.pyx:144-146)
-template <typename T, int R, bool PACKED, int OPT, bool HOG>
-__global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const uint32_t *__restrict__ cells, int64_t n,
+// CellT = uint32_t while U*I < 2^32 (one word of the index stream per draw), uint64_t beyond (64-bit draws, rng.hip)
+template <typename T, int R, bool PACKED, int OPT, bool HOG, typename CellT>
+__global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const CellT *__restrict__ cells, int64_t n,
                                                    double *__restrict__ loss_acc) {
     const int lane = lane_id();
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const uint32_t 
     const int K = d.K;
     double loss_sum = 0.0;
     for (int64_t s = wave0; s < n; s += n_waves) {
-        const uint32_t cell = cells[s];
-        const int64_t u = cell / (uint32_t)d.I, i = cell % (uint32_t)d.I;
+        const CellT cell = cells[s];
+        const int64_t u = (int64_t)(cell / (CellT)d.I), i = (int64_t)(cell % (CellT)d.I);
         const T r = d.X[u * d.I + i], p = d.prop[i];
         const int64_t ou = u * K, oi = i * K;
         Row<T, R, PACKED> w, h, sw[NS ? NS : 1], sh[NS ? NS : 1];
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const uint32_t 
 
 // any K (cymf/relmf.pyx:42 takes any num_components): rows wider than the register layouts (K > 256) are streamed from
 // memory in two passes, lanes striding over k -- pass 1 the prediction and the l2 term, pass 2 the element-wise update.
-template <typename T, int OPT, bool HOG>
-__global__ __launch_bounds__(256) void relmf_wide_kernel(RelDev<T> d, const uint32_t *__restrict__ cells, int64_t n,
+template <typename T, int OPT, bool HOG, typename CellT>
+__global__ __launch_bounds__(256) void relmf_wide_kernel(RelDev<T> d, const CellT *__restrict__ cells, int64_t n,
                                                         double *__restrict__ loss_acc) {
     const int lane = lane_id();
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -112,8 +113,8 @@ __global__ __launch_bounds__(256) void relmf_wide_kernel(RelDev<T> d, const uint
     const int K = d.K;
     double loss_sum = 0.0;
     for (int64_t s = wave0; s < n; s += n_waves) {
-        const uint32_t cell = cells[s];
-        const int64_t u = cell / (uint32_t)d.I, i = cell % (uint32_t)d.I;
+        const CellT cell = cells[s];
+        const int64_t u = (int64_t)(cell / (CellT)d.I), i = (int64_t)(cell % (CellT)d.I);
         const T r = d.X[u * d.I + i], p = d.prop[i];
         const int64_t ou = u * K, oi = i * K;
         T py = 0, pl = 0;
@@ -802,25 +803,25 @@ void launch_glove_step(int K, const GloveStepDev &d, const int32_t *c, const int
         else { if (P__) { CALL(4, true); } else { CALL(4, false); } }                          \
     } while (0)
 
-template <typename T, int R, bool PACKED, bool HOG>
-void launch_relmf_opt(int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, double *loss, int grid,
+template <typename T, int R, bool PACKED, bool HOG, typename CellT>
+void launch_relmf_opt(int opt, const RelDev<T> &d, const CellT *cells, int64_t n, double *loss, int grid,
                       hipStream_t s) {
     switch (opt) {
-    case CYMF_OPT_SGD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_SGD, HOG>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
-    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAGRAD, HOG>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
-    default: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAM, HOG>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    case CYMF_OPT_SGD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_SGD, HOG, CellT>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    case CYMF_OPT_ADAGRAD: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAGRAD, HOG, CellT>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
+    default: hipLaunchKernelGGL((relmf_kernel<T, R, PACKED, CYMF_OPT_ADAM, HOG, CellT>), dim3(grid), dim3(256), 0, s, d, cells, n, loss); break;
     }
 }
 
 // hog: lock-free launch over all cells (Adam's moment clamp of rows.h on); false: one conflict-free level
-template <typename T>
-void launch_relmf(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, double *loss, int grid,
+template <typename T, typename CellT>
+void launch_relmf(int K, int opt, const RelDev<T> &d, const CellT *cells, int64_t n, double *loss, int grid,
                   hipStream_t s, bool hog = false) {
     if (K > 256) {
 #define WIDE_(O_)                                                                                                                   \
     do {                                                                                                                            \
-        if (hog) hipLaunchKernelGGL((relmf_wide_kernel<T, O_, true>), dim3(grid), dim3(256), 0, s, d, cells, n, loss);              \
-        else hipLaunchKernelGGL((relmf_wide_kernel<T, O_, false>), dim3(grid), dim3(256), 0, s, d, cells, n, loss);                 \
+        if (hog) hipLaunchKernelGGL((relmf_wide_kernel<T, O_, true, CellT>), dim3(grid), dim3(256), 0, s, d, cells, n, loss);       \
+        else hipLaunchKernelGGL((relmf_wide_kernel<T, O_, false, CellT>), dim3(grid), dim3(256), 0, s, d, cells, n, loss);          \
     } while (0)
         if (opt == CYMF_OPT_SGD) WIDE_(CYMF_OPT_SGD); else if (opt == CYMF_OPT_ADAGRAD) WIDE_(CYMF_OPT_ADAGRAD); else WIDE_(CYMF_OPT_ADAM);
 #undef WIDE_
@@ -828,8 +829,8 @@ void launch_relmf(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int
     }
 #define CALL_(R_, P_)                                                                 \
     do {                                                                              \
-        if (hog) launch_relmf_opt<T, R_, P_, true>(opt, d, cells, n, loss, grid, s);  \
-        else launch_relmf_opt<T, R_, P_, false>(opt, d, cells, n, loss, grid, s);     \
+        if (hog) launch_relmf_opt<T, R_, P_, true, CellT>(opt, d, cells, n, loss, grid, s);  \
+        else launch_relmf_opt<T, R_, P_, false, CellT>(opt, d, cells, n, loss, grid, s);     \
     } while (0)
     CYMF_DISPATCH_LAYOUT(K, CALL_);
 #undef CALL_
@@ -845,6 +846,12 @@ void launch_glove(int K, const GloveDev<T> &d, const int32_t *c, const int32_t *
 #define CALL_(R_, P_) hipLaunchKernelGGL((glove_kernel<T, R_, P_>), dim3(grid), dim3(256), 0, s, d, c, x, cnt, n, loss)
     CYMF_DISPATCH_LAYOUT(K, CALL_);
 #undef CALL_
+}
+
+__global__ void widen_cells_kernel(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
 }
 
 // HOGWILD launches: the number of wavefronts bounds the staleness.  With waves striding over the
@@ -889,6 +896,10 @@ struct cymf_relmf {
     RelStore<double> f64;
     DeviceRng rng;
     DevBuf<uint32_t> d_cells, d_sorted, d_ucnt;
+    // U*I >= 2^32 (cymf/relmf.pyx:128 draws on `long`): 64-bit cells, generated and consumed in batches by the generic kernels.
+    // force_wide_cells (CYMF_RELMF_FORCE_WIDE_CELLS=1, test hook): run the 64-bit-cell kernels on a small problem's widened cells.
+    bool wide = false, force_wide_cells = false;
+    DevBuf<uint64_t> d_cells64;
     DevBuf<unsigned long long> d_ucursor;
     // step path (f32 throughput, K <= 128): the cells of epoch e+1 are generated and bucketed by user on
     // side_stream while relmf_step_kernel works through epoch e; buffers double-buffered by epoch parity
@@ -974,7 +985,10 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
     const int64_t N = (int64_t)h->U * h->I;   // relmf.pyx:120: one epoch = U*I draws with replacement
     const bool tiled = h->mode == CYMF_MODE_THROUGHPUT && h->tile_ok && !h->comm && sizeof(T) == 4;
     const bool stepped = tiled || (h->mode == CYMF_MODE_THROUGHPUT && h->step_path && sizeof(T) == 4);
-    if (!stepped) {
+    if (h->wide && h->mode != CYMF_MODE_THROUGHPUT)
+        return fail(CYMF_ERR_UNSUPPORTED, "cymf_relmf: U*I = %lld draws per epoch: the exact (sequential-order) mode schedules the epoch's draws on the "
+                    "host and is limited to U*I < 2^32; the lock-free mode takes any size", (long long)N);
+    if (!stepped && !h->wide) {
         CYMF_TRY(h->d_cells.alloc((size_t)N));
         CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, h->stream));
     }
@@ -1062,8 +1076,24 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
             CYMF_HIP(hipEventRecord(h->ev_step_done[b], h->stream));
             h->epoch_cursor++;
         }
+    } else if (h->mode == CYMF_MODE_THROUGHPUT && h->wide) {
+        // U*I >= 2^32: 64-bit draws (the one-lane walker of rng.hip), generated and consumed in batches of 2^26
+        const int64_t BATCH = (int64_t)1 << 26;
+        CYMF_TRY(h->d_cells64.alloc((size_t)BATCH));
+        for (int64_t done = 0; done < N; done += BATCH) {
+            const int64_t nb = std::min(BATCH, N - done);
+            CYMF_TRY(h->rng.generate64(0, nb, h->d_cells64.p, h->stream));
+            launch_relmf<T, uint64_t>(h->K, h->opt, d, h->d_cells64.p, nb, h->d_loss.p, hogwild_grid(nb, 1.0 / std::min(h->U, h->I)), h->stream, /*hog=*/true);
+            CYMF_HIP(hipGetLastError());
+        }
     } else if (h->mode == CYMF_MODE_THROUGHPUT) {
-        launch_relmf<T>(h->K, h->opt, d, h->d_cells.p, N, h->d_loss.p, hogwild_grid(N, 1.0 / std::min(h->U, h->I)), h->stream, /*hog=*/true);
+        if (h->force_wide_cells) {   // test hook: the 64-bit-cell kernels on this problem's (widened) 32-bit draws
+            CYMF_TRY(h->d_cells64.alloc((size_t)N));
+            hipLaunchKernelGGL(widen_cells_kernel, dim3(ew_blocks(N)), dim3(256), 0, h->stream, h->d_cells.p, h->d_cells64.p, N);
+            launch_relmf<T, uint64_t>(h->K, h->opt, d, h->d_cells64.p, N, h->d_loss.p, hogwild_grid(N, 1.0 / std::min(h->U, h->I)), h->stream, /*hog=*/true);
+        } else {
+            launch_relmf<T, uint32_t>(h->K, h->opt, d, h->d_cells.p, N, h->d_loss.p, hogwild_grid(N, 1.0 / std::min(h->U, h->I)), h->stream, /*hog=*/true);
+        }
         CYMF_HIP(hipGetLastError());
     } else {
         h->h_cells.resize((size_t)N);
@@ -1079,9 +1109,15 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
         std::vector<uint32_t> sorted((size_t)N);
         for (int64_t p = 0; p < N; ++p) sorted[p] = h->h_cells[(size_t)order[p]];
         CYMF_TRY(h->d_sorted.upload(sorted.data(), sorted.size(), h->stream));
+        if (h->force_wide_cells) {
+            CYMF_TRY(h->d_cells64.alloc((size_t)N));
+            hipLaunchKernelGGL(widen_cells_kernel, dim3(ew_blocks(N)), dim3(256), 0, h->stream, h->d_sorted.p, h->d_cells64.p, N);
+        }
         for (size_t lv = 1; lv + 1 < off.size(); ++lv) {
             const int64_t b = off[lv], n = off[lv + 1] - off[lv];
-            if (n > 0) launch_relmf<T>(h->K, h->opt, d, h->d_sorted.p + b, n, h->d_loss.p, (int)((n + 3) / 4), h->stream);
+            if (n <= 0) continue;
+            if (h->force_wide_cells) launch_relmf<T, uint64_t>(h->K, h->opt, d, h->d_cells64.p + b, n, h->d_loss.p, (int)((n + 3) / 4), h->stream);
+            else launch_relmf<T, uint32_t>(h->K, h->opt, d, h->d_sorted.p + b, n, h->d_loss.p, (int)((n + 3) / 4), h->stream);
         }
         CYMF_HIP(hipGetLastError());
     }
@@ -1115,8 +1151,11 @@ extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t
         for (DevBuf<double> *b : {&h->f64.W, &h->f64.H, &h->f64.W0, &h->f64.W1, &h->f64.H0, &h->f64.H1}) b->fine = 2;
     }
     int rc = h->d_loss.alloc(1);
-    h->step_path = mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && K <= 128 && !(getenv("CYMF_RELMF_NO_STEP") && getenv("CYMF_RELMF_NO_STEP")[0] == '1');
-    h->tile_ok = mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && relmf_tile_plan(U, I, K, optimizer, &h->plan) &&
+    h->wide = (uint64_t)U * (uint64_t)I > 0xffffffffull;   // 64-bit draws (cymf/relmf.pyx:128 draws on long)
+    h->force_wide_cells = getenv("CYMF_RELMF_FORCE_WIDE_CELLS") && getenv("CYMF_RELMF_FORCE_WIDE_CELLS")[0] == '1';
+    h->step_path = !h->wide && mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && K <= 128 && !(getenv("CYMF_RELMF_NO_STEP") && getenv("CYMF_RELMF_NO_STEP")[0] == '1');
+    if (h->force_wide_cells) h->step_path = false;
+    h->tile_ok = !h->force_wide_cells && mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && relmf_tile_plan(U, I, K, optimizer, &h->plan) &&
                  !(getenv("CYMF_RELMF_NO_TILES") && getenv("CYMF_RELMF_NO_TILES")[0] == '1');
     if (!rc && (h->step_path || h->tile_ok)) {
         hipError_t e2 = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);

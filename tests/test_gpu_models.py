@@ -117,6 +117,28 @@ def test_relmf_tile_schedule_shapes_every_draw_applied_once(U, I, K, optimizer):
         assert np.linalg.norm(dH - (H - H0)) <= 0.15 * np.linalg.norm(H - H0)
 
 
+def test_relmf_64bit_cell_kernels_vs_oracle(monkeypatch):
+    """RelMF draws cells from UniformGenerator(0, U*I) on `long` (cymf/relmf.pyx:128); once U*I reaches 2^32 the draws are
+    64-bit (their stream is pinned in test_gpu_rng.py up to 2^40) and the trainers run the generic kernels on 64-bit
+    cells in batches.  A dense X of 2^32 cells is 34 GB on the host, so the cell-type plumbing is exercised here on a small
+    problem whose 32-bit draws are widened (CYMF_RELMF_FORCE_WIDE_CELLS): exact mode must still equal the oracle."""
+    monkeypatch.setenv("CYMF_RELMF_FORCE_WIDE_CELLS", "1")
+    rs = np.random.RandomState(5)
+    U, I, K = 60, 45, 20
+    Xd = (rs.rand(U, I) < 0.1).astype(np.float64)
+    prop = np.maximum(Xd.mean(axis=0) / Xd.mean(axis=0).max(), 1e-5) ** 0.5
+    for opt, lr in (("sgd", 0.02), ("adam", 0.002)):
+        W, H = oracle.reference_init(U, I, K)
+        om = oracle.RelMf(W, H, opt, lr, 0.01, 0.1)
+        want = [om.epoch(Xd, prop) for _ in range(2)]
+        m = RelMF(K, 0.1, lr, opt, 0.01)
+        m.fit(Xd, num_epochs=2, num_threads=1)
+        assert _close(m.W, W, 1e-10) and _close(m.H, H, 1e-10), opt
+        mt = RelMF(K, 0.1, lr, opt, 0.01)
+        mt.fit(Xd, num_epochs=2, num_threads=4)
+        assert np.isfinite(mt.W).all() and mt.losses[-1] == pytest.approx(want[-1], rel=5e-2)
+
+
 # ------------------------------------------------------------------ GloVe
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 @pytest.mark.parametrize("K", [16, 100])
