@@ -196,8 +196,10 @@ def main():
             tj = json.load(open(tpath))
             traffic = tj.get(f"bpr_step_{args.optimizer}_K{K}")
             if traffic is not None:
+                prof_slots = int(tj.get("slots_per_launch", 4000000))
+                traffic = traffic * (k_slots / max(k_launches, 1)) / prof_slots      # per launch of THIS run's step size
                 traffic_source = ("profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of "
-                                  f"{tj.get('triplets_per_launch', '4.0 M')} slots, not measured in this run)")
+                                  f"{prof_slots} slots, scaled to this run's {int(k_slots / max(k_launches, 1))} slots per launch; not measured in this run)")
         except Exception:
             traffic = None
 

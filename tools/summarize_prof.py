@@ -30,7 +30,7 @@ def counters(d, name):
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 
 
-lines = [f"# rocprofv3 summary {tag}", "", "## --kernel-trace --stats (python3 bench.py --cpu-sample 0 --steps 50 --warmup 5)", "",
+lines = [f"# rocprofv3 summary {tag}", "", f"## --kernel-trace --stats ({os.environ.get('PROF_CMD', 'python3 bench.py --cpu-sample 0 --steps 50 --warmup 5')})", "",
          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
 f = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
 for r in csv.DictReader(open(f)):
@@ -63,6 +63,7 @@ tpath = os.path.join(ROOT, "profiles", "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 k = "bpr_step_kernel"
 traffic["bpr_step_sgd_K128"] = (2 * fetch[k] + write[k]) * 1024
-traffic["_source"] = f"profiles/{tag}_summary.md (C3, 4M triplets per launch)"
+traffic["slots_per_launch"] = int(float(os.environ.get("PROF_SLOTS", "4.0 M").split()[0]) * 1e6)
+traffic["_source"] = f"profiles/{tag}_summary.md (C3, {traffic['slots_per_launch']} slots per launch)"
 json.dump(traffic, open(tpath, "w"), indent=1)
 print("\n".join(lines))
