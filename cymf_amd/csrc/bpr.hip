@@ -46,10 +46,14 @@ __device__ __forceinline__ double inv1pexp(double x) { return 1.0 / (1.0 + exp(x
 
 // forward (model.pyx:47-62) + backward (model.pyx:66-87) on rows already in registers.
 // Gradients of every component use the pre-update values (model.pyx:81-87).
+// HOG (lock-free float32 kernels): the per-triplet chain is what one wavefront runs back to back, so it is kept short --
+// s = 1 / (1 + e^x) and the softplus through v_exp_f32 / v_log_f32 (relative error ~1e-6: far inside the lock-free mode's
+// statistical bar; the exact mode keeps expf / log1pf), and the weight-decay term of the loss is accumulated per lane in
+// `l2_acc` and reduced once per wavefront at the end instead of once per triplet (one wave-wide reduction less on the chain).
 template <typename T, int R, bool PACKED, int OPT, bool HOG = false>
 __device__ __forceinline__ T bpr_update_rows(const BprDev<T> &d, Row<T, R, PACKED> &w, Row<T, R, PACKED> &hi,
                                              Row<T, R, PACKED> &hj, Row<T, R, PACKED> *sw, Row<T, R, PACKED> *shi,
-                                             Row<T, R, PACKED> *shj) {
+                                             Row<T, R, PACKED> *shj, T *l2_acc = nullptr) {
     T px = 0, pl = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -57,9 +61,18 @@ __device__ __forceinline__ T bpr_update_rows(const BprDev<T> &d, Row<T, R, PACKE
         pl += w.v[r] * w.v[r] + hi.v[r] * hi.v[r] + hj.v[r] * hj.v[r];
     }
     const T x = wave_sum(px);
-    const T l2 = wave_sum(pl);
-    const T loss = softplus_neg(x) + d.wd * l2;
-    const T s = inv1pexp(x);
+    T loss, s;
+    if constexpr (HOG && sizeof(T) == 4) {
+        *l2_acc += pl;
+        const float e = __expf(-fabsf(x));                       // e^{-|x|} in (0, 1]
+        loss = fmaxf(-x, 0.0f) + __logf(1.0f + e);               // -log(sigmoid(x))
+        const float r1 = __builtin_amdgcn_rcpf(1.0f + e);        // sigmoid(|x|)
+        s = x >= 0.0f ? e * r1 : r1;                             // 1 / (1 + e^x)
+    } else {
+        const T l2 = wave_sum(pl);
+        loss = softplus_neg(x) + d.wd * l2;
+        s = inv1pexp(x);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const T wv = w.v[r], iv = hi.v[r], jv = hj.v[r];
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
         if (slot_begin > step_begin && slot_item[slot_begin - 1] == fi) shared_first = fi;
         if (slot_end < step_end && slot_item[slot_end] == li) shared_last = li;
     }
-    float loss_sum = 0.0f;
+    float loss_sum = 0.0f, l2_acc = 0.0f;
     unsigned int n_done = 0;
     float *const Ws[2] = {d.W0, d.W1};
     float *const Hs[2] = {d.H0, d.H1};
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
                     }
                     const int pj = p % RINGJ;
                     const RowT hj_old = jq[pj];
-                    loss_sum += bpr_update_rows<float, R, PACKED, OPT, true>(d, wq[p], hi, jq[pj], swq[p], shi, sjq[pj]);
+                    loss_sum += bpr_update_rows<float, R, PACKED, OPT, true>(d, wq[p], hi, jq[pj], swq[p], shi, sjq[pj], &l2_acc);
                     if (!(diag & 2)) wq[p].store(d.W + (int64_t)u * K, K, lane);
 #pragma unroll
                     for (int q = 0; q < NS; ++q) swq[p][q].store(Ws[q] + (int64_t)u * K, K, lane);
@@ -542,8 +555,9 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
 #pragma unroll
         for (int q = 0; q < NS; ++q) shi[q].store(Hs[q] + (int64_t)cur_item * K, K, lane);
     }
+    const float l2_all = wave_sum(l2_acc);   // weight-decay term of the loss, all triplets of this wavefront
     if (lane == 0 && n_done) {
-        atomicAdd(loss_acc, (double)loss_sum);
+        atomicAdd(loss_acc, (double)(loss_sum + d.wd * l2_all));
         atomicAdd(performed_acc, (unsigned long long)n_done);
     }
 }

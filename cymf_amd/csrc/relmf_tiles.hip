@@ -23,9 +23,9 @@
 namespace cymf {
 namespace {
 
-constexpr int BK_THREADS = 1024;
+constexpr int BK_THREADS = 512;                      // (with 16 cells per thread: 96 VGPRs -- two such wavefronts per SIMD fit beside a tile workgroup's four)
 constexpr int BK_CPT = 16;                       // cells per thread and segment
-constexpr int BK_SEG = BK_THREADS * BK_CPT;      // 16384 cells = 64 KB of LDS
+constexpr int BK_SEG = BK_THREADS * BK_CPT;      // 8192 cells = 32 KB of LDS
 
 __device__ __forceinline__ uint32_t cell_digit(uint32_t c, uint32_t I, uint32_t ub, uint32_t ib, int pass) {
     const uint32_t u = c / I;
