@@ -64,8 +64,9 @@ __device__ __forceinline__ T bpr_update_rows(const BprDev<T> &d, Row<T, R, PACKE
     T loss, s;
     if constexpr (HOG && sizeof(T) == 4) {
         *l2_acc += pl;
-        const float e = __expf(-fabsf(x));                       // e^{-|x|} in (0, 1]
-        loss = fmaxf(-x, 0.0f) + __logf(1.0f + e);               // -log(sigmoid(x))
+        // raw v_exp_f32 / v_log_f32 (base 2, no denormal rescue: e below 2^-126 may flush to 0, 1 + e lies in [1, 2])
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));          // e^{-|x|} in (0, 1]
+        loss = fmaxf(-x, 0.0f) + 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + e);   // -log(sigmoid(x))
         const float r1 = __builtin_amdgcn_rcpf(1.0f + e);        // sigmoid(|x|)
         s = x >= 0.0f ? e * r1 : r1;                             // 1 / (1 + e^x)
     } else {
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void bpr_step_kernel(BprDev<float> d, const in
     xcd_stride &= 255;
     if (blockIdx.x % xcd_stride) return;   // diagnostic: xcd_stride 8 keeps every active block on one XCD
     const int lane = lane_id();
-    const int K = d.K;
+    const int K = PACKED ? 64 * R : d.K;   // packed layouts: a compile-time row length (row offsets become shifts, no 64-bit scalar multiplies per row)
     const int64_t wave = ((int64_t)(blockIdx.x / xcd_stride) * blockDim.x + threadIdx.x) >> 6;
     // this wave's slots [slot_begin, slot_end): either an equal share of the step (SGD: an item run may be
     // split between waves, which then exchange at chunk boundaries) or an explicit ITEM-ALIGNED range
