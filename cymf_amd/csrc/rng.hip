@@ -272,7 +272,7 @@ __global__ __launch_bounds__(JUMP_THREADS) void mt_jump_kernel(const uint32_t *_
     }
 }
 
-constexpr int REJ_CAP_MIN = 8192;   // recorded rejection offsets per chunk (at least; sized from the range's rejection rate)
+constexpr int REJ_CAP_MIN = 2048;   // recorded rejection offsets per chunk (at least; sized from the range's rejection rate)
 
 // Workgroup q generates chunk (c0 + q) of the raw stream from its start state and writes the
 // accepted words (Lemire) compacted to tmp[q*J ...]; words before skip0 belong to an earlier call
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(RNG_THREADS) void rng_chunk_kernel(const uint32_t *
                                                                uint32_t range, uint32_t thr,
                                                                uint32_t *__restrict__ tmp, uint32_t *__restrict__ counts,
                                                                uint32_t *__restrict__ rej, uint32_t *__restrict__ rej_cnt,
-                                                               uint32_t rej_cap) {
+                                                               uint32_t rej_cap, uint32_t limit) {
     __shared__ uint32_t buf[2][MT_N];
     __shared__ int s_wcnt[RNG_THREADS / 64];
     __shared__ uint32_t s_nrej;
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(RNG_THREADS) void rng_chunk_kernel(const uint32_t *
     uint32_t base = 0;   // accepted so far (uniform)
     __syncthreads();
     for (int blk = 0; blk < MT_JUMP_BLOCKS; ++blk) {
+        if (base >= limit) break;                  // the call asked for no more than `limit` draws in all (uniform)
         const uint32_t *c = buf[cur];
         uint32_t *nx = buf[cur ^ 1];
         if (tid < 227) nx[tid] = c[tid + MT_M] ^ mt_mix(c[tid], c[tid + 1]);
@@ -418,7 +419,7 @@ int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel)
     // (a range like U*I = 1.6e8 of RelMF rejects 3 % of the words: 130 k per chunk)
     const double rej_per_chunk = (double)thr_ / 4294967296.0 * (double)MT_JUMP_WORDS;
     rej_cap_ = REJ_CAP_MIN;
-    while ((double)rej_cap_ < rej_per_chunk * 1.5 + 4096.0) rej_cap_ *= 2;
+    while ((double)rej_cap_ < rej_per_chunk * 1.5 + 1024.0) rej_cap_ *= 2;
     parallel_ = parallel && rej_cap_ <= (1 << 19);   // beyond ~8 % rejections the one-workgroup walker serves (2 MB of list per chunk)
     if (parallel_) {
         CYMF_TRY(poly_.upload(&MT_JUMP_POLYS[0][0], (size_t)MT_JUMP_LEVELS * MT_N, s));
@@ -448,8 +449,8 @@ int DeviceRng::ensure_states(int64_t last_chunk, hipStream_t s) {
         states_cap_ = cap;
     }
     // Level l jumps by D = 4^l chunks: a run of up to D states follows from the run D chunks before it in ONE launch, one
-    // workgroup per state (~0.5 ms).  The largest D <= states_known_ is taken each time: 3 + 3 + 3 launches reach 64 states,
-    // 64 more per launch after that.  (A chain of single jumps, one launch per chunk, was the first version: 11 ms per 100 M
+    // workgroup per state (~0.5 ms).  The largest D <= states_known_ is taken each time: 3 launches per level reach 256 states,
+    // 256 more per launch after that (one workgroup per CU: the 82 KB of LDS allow no second one).  (A chain of single jumps, one launch per chunk, was the first version: 11 ms per 100 M
     // draws -- hidden under the step kernels on one GPU, but every rank of a sharded job generates the whole stream while its
     // own steps shrink with the world size.)
     while (states_known_ <= last_chunk) {
@@ -517,7 +518,8 @@ int DeviceRng::generate_parallel(int64_t n_total, int64_t n_skip, uint32_t *d_ou
         CYMF_TRY(rej_.alloc((size_t)pend_.cap_chunks * rej_cap_));
     }
     hipLaunchKernelGGL(rng_chunk_kernel, dim3((unsigned)n_chunks), dim3(RNG_THREADS), 0, s, states_.p + (size_t)c0 * MT_N,
-                       (uint32_t)skip0, range_, thr_, tmp_.p, counts_.p, rej_.p, rej_cnt_.p, (uint32_t)rej_cap_);
+                       (uint32_t)skip0, range_, thr_, tmp_.p, counts_.p, rej_.p, rej_cnt_.p, (uint32_t)rej_cap_,
+                       (uint32_t)std::min<int64_t>(n_total, 0xffffffffll));
     CYMF_HIP(hipGetLastError());
     if (d_out && n_total > n_skip) {
         hipLaunchKernelGGL(rng_gather_kernel, dim3(64, (unsigned)n_chunks), dim3(256), 0, s, tmp_.p, counts_.p, (int)n_chunks,
