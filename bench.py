@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="triplets timed on the CPU oracle (0 = skip)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs (C2 / C4 / C5 / RelMF)")
+    ap.add_argument("--pretend-world", type=int, default=1,
+                    help="diagnostic (N=1 only): run rank 0's share of a P-rank job with a one-rank communicator -- the per-rank "
+                         "compute cost of the sharded schedule without the exchange; the line is marked and is not a result")
     args = ap.parse_args()
 
     rank, world, local = dist.env_rank_world()
@@ -124,8 +127,11 @@ def main():
     nnz = len(cols)
     log(rank, f"synthetic {args.config}: U={U} I={I} nnz={nnz} K={K} ready in {time.time()-t0:.1f}s")
     comm = None
+    pretend = args.pretend_world if world == 1 and args.pretend_world > 1 else 0
+    if pretend:
+        world = pretend                                   # rank 0 of `pretend`; restored below for the report
     if world > 1:
-        comm = dist.Comm.from_env(device=device)
+        comm = dist.Comm.local_group(1, I * K + 64, device=device)[0] if pretend else dist.Comm.from_env(device=device)
         lo, hi = dist.user_shards(indptr, world)[rank]
         all_users = data["users"]
         mine = np.nonzero((all_users >= lo) & (all_users < hi))[0]       # global positions of my triplets
@@ -149,6 +155,8 @@ def main():
     t0 = time.time()
     trainer.set_data(users, positives, csr_indptr, csr_indices, gpos, nnz)
     trainer.upload(W0, H0)
+    if pretend:
+        world = 1
     log(rank, f"device setup {time.time()-t0:.1f}s on {_lib.device_name(device)}")
 
     def barrier():
@@ -248,6 +256,14 @@ def main():
         del data, users, positives, W0, H0
         secondary = secondary_paths(device, args.scale)
 
+    if rank == 0 and pretend:
+        print(json.dumps({"diagnostic": f"rank 0 of a pretended {pretend}-rank job, one-rank communicator (no exchange traffic)",
+                          "steps": args.steps, "steps_per_epoch": spe, "ms_per_step": elapsed / args.steps * 1e3,
+                          "local_triplets_per_step": performed_local / args.steps, "kernel_ms_per_step": k_ms / max(k_launches, 1),
+                          "job_rate_if_exchange_hidden": performed_local * pretend / elapsed}))
+        trainer.close()
+        comm.close()
+        return
     if rank == 0:
         out = {
             "metric": "BPR triplet-updates/sec at K=128",
