@@ -529,8 +529,8 @@ __device__ __forceinline__ void stage_rounds(f32x2 (&a)[16 * T32], const f32x16 
 // its share of the gathered rows; the tiles go through a small LDS stage to turn the MFMA C layout into "lane j holds row j"
 // (rows read the tile, the mirrored block reads its transpose), and the system is solved in registers.  Little LDS and
 // <= 168 VGPRs at K <= 64 on purpose: the column steps are a latency chain, three waves per SIMD fill it.
-template <int T32, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(int32_t rows, const int32_t *__restrict__ indptr,
+template <int T32, int NW, bool PRE>
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wmf_row_reg_kernel(int32_t rows, const int32_t *__restrict__ indptr,
                                                              const int32_t *__restrict__ indices, float *__restrict__ X,
                                                              const float *__restrict__ Y, const float *__restrict__ A0,
                                                              float weight, int32_t long_threshold, int probe) {
@@ -580,30 +580,85 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
                 }
             }
         }
-        // 64 gathered rows per batch; each of the T32 32-column chunks of a gathered row is loaded once per
-        // step and feeds every tile that uses it (tile (m, n) multiplies chunk m by chunk n)
-        for (int32_t pb = p0; pb < p1; pb += 64) {
-            const int32_t myp = pb + lane;
-            const int32_t myidx = myp < p1 ? indices[myp] : -1;
-            const int nb = p1 - pb < 64 ? p1 - pb : 64;
-            const int steps = (nb + 1) >> 1;
-            for (int s0 = wave; s0 < steps; s0 += 8 * NW) {     // steps wave, wave + NW, ... (at most 32 per batch)
-                float ch[8][T32];
+        // 64 gathered rows per batch (lane l holds the index of entry l), 32 k=2 steps per batch dealt to the waves in turn, 8 steps
+        // per group: each of the T32 32-column chunks of a gathered row is loaded once per step and feeds every tile that uses it
+        // (tile (m, n) multiplies chunk m by chunk n).  The loads of group g + 1 (and the indices of the batch after next) are
+        // issued BEFORE the MFMAs of group g: at K >= 96 one wave per SIMD is resident, so nothing else hides an L2 miss
+        // (without the look-ahead the matrix pipe sat idle for one memory latency per group: 0.27 busy at K=128).
+        if constexpr (PRE) {
+            constexpr int GPB = 4 / NW;                          // groups per batch and wave
+            const int n = p1 - p0;
+            const int n_groups = ((n + 63) >> 6) * GPB;
+            const auto batch_indices = [&](int b) -> int32_t {
+                const int32_t myp = p0 + 64 * b + lane;
+                return myp < p1 ? indices[myp] : -1;
+            };
+            const auto load_group = [&](int g, int32_t idxvec, float (&c)[8][T32]) {
+                const int q = g % GPB;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int32_t idx = __shfl(myidx, 2 * (s0 + NW * u) + lh, 64);
-                    const bool ok = idx >= 0 && s0 + NW * u < steps;
+                    const int32_t idx = __shfl(idxvec, 2 * (wave + NW * (8 * q + u)) + lh, 64);
+                    const bool ok = idx >= 0;
                     const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
 #pragma unroll
-                    for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
+                    for (int m = 0; m < T32; ++m) c[u][m] = ok ? yrow[32 * m + li] : 0.0f;
                 }
+            };
+            int32_t idx_cur = batch_indices(0), idx_nxt = n > 64 ? batch_indices(1) : -1;
+            float cur[8][T32], nxt[8][T32];
+            if (n_groups > 0) load_group(0, idx_cur, cur);
+            for (int g = 0; g < n_groups; ++g) {
+                const int gn = g + 1;
+                if (gn < n_groups) {
+                    if (gn % GPB == 0) {
+                        idx_cur = idx_nxt;
+                        idx_nxt = 64 * (gn / GPB + 1) < n ? batch_indices(gn / GPB + 1) : -1;
+                    }
+                    load_group(gn, idx_cur, nxt);
+                }
+                const int left = n - 64 * (g / GPB);             // entries of this group's batch
+                const int steps = ((left < 64 ? left : 64) + 1) >> 1;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
+                    if (wave + NW * (8 * (g % GPB) + u) < steps) {   // (uniform) a short last batch issues no MFMAs on zeros
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u][tile_m(t)], cur[u][tile_n(t)], acc[t], 0, 0, 0);
 #pragma unroll
-                    for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
+                        for (int m = 0; m < T32; ++m) bsum[m] += cur[u][m];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int m = 0; m < T32; ++m) cur[u][m] = nxt[u][m];
+            }
+        } else {
+            // 64 gathered rows per batch; each of the T32 32-column chunks of a gathered row is loaded once per
+            // step and feeds every tile that uses it (tile (m, n) multiplies chunk m by chunk n)
+            for (int32_t pb = p0; pb < p1; pb += 64) {
+                const int32_t myp = pb + lane;
+                const int32_t myidx = myp < p1 ? indices[myp] : -1;
+                const int nb = p1 - pb < 64 ? p1 - pb : 64;
+                const int steps = (nb + 1) >> 1;
+                for (int s0 = wave; s0 < steps; s0 += 8 * NW) {     // steps wave, wave + NW, ... (at most 32 per batch)
+                    float ch[8][T32];
+    #pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int32_t idx = __shfl(myidx, 2 * (s0 + NW * u) + lh, 64);
+                        const bool ok = idx >= 0 && s0 + NW * u < steps;
+                        const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
+    #pragma unroll
+                        for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+    #pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
+    #pragma unroll
+                        for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
+                    }
                 }
             }
         }
@@ -618,6 +673,173 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
         const float bj0 = bvec[jr];
         const float x = probe == 1 ? a[0][0] + bj0 : solve_reg<K, NW>(a, bj0, j, colbuf, bbuf);   // (1: timing probe, no solve)
         if (j < K) X[(int64_t)i * K + j] = x;                  // wmf.pyx:170-171
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked elimination in the MFMA accumulator layout (K = 96, 128): ONE wavefront per row, no LDS, no layout change.
+// The system stays where the Gramian was accumulated -- upper-triangular 32 x 32 tiles T(m, n), m <= n, in the C/D layout of
+// v_mfma_f32_32x32x2_f32 (lane l: column l & 31; register r: row (r & 3) + 8 (r >> 2) + 4 (l >> 5)) -- and is eliminated panel
+// by panel (block Gaussian elimination of an SPD matrix, no pivoting):
+//     N      = -T(p,p)^-1                       32 x 32 symmetric sweep, VALU + ds_bpermute (sweep_step)
+//     R(p,n) = N T(p,n)                         16 MFMAs per tile: register r of N is the A operand (N is symmetric, so its
+//                                               C-layout register holds N[i][k] for lane i and this half's k), register r of
+//                                               T(p,n) the B operand -- VGPR operands as they lie, no broadcast through LDS
+//     T(m,n) += T(p,m)^T R(p,n),  p < m <= n    16 MFMAs per tile, operands again registers r of T(p,m) and R(p,n)
+//     b_n    += R(p,n)^T b_p,  z_p = -N b_p     16 FMAs per tile and lane
+// and x_p = z_p + sum_{n > p} R(p,n) x_n on the way back.  Per K=128 row: 256 MFMAs for the factorisation (the register
+// Gauss-Jordan above spends 2 x 8192 v_pk_fma_f32 and a 128-step latency chain on two waves), and two independent waves per
+// SIMD: one wave's sweep (a chain of ds_bpermute round trips) runs under the other's MFMAs.
+constexpr int blk_tix(int m, int n) { return n * (n + 1) / 2 + m; }   // = the order of tile_m / tile_n
+
+template <int C>
+__device__ __forceinline__ void sweep_step(f32x16 &P, int li, int lh) {
+    constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;     // row C: register RC of the lanes of half LC
+    const float rowv = __shfl(P[RC], li + 32 * LC, 64);               // P[C][j] for this lane's column j
+    float colv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) colv[r] = __shfl(P[r], C + 32 * lh, 64);   // P[k(r, lh)][C]
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rowv), C));
+    const float inv = rcp_nr(d);
+    const float t = rowv * inv;
+    const f32x2 nt2 = {-t, -t};
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        f32x2 v = {P[2 * g], P[2 * g + 1]};
+        v = __builtin_elementwise_fma(f32x2{colv[2 * g], colv[2 * g + 1]}, nt2, v);
+        P[2 * g] = v[0];
+        P[2 * g + 1] = v[1];
+    }
+    if (li == C) {                        // column C: P[i][C] / d (the generic update left exact zeros here)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[r] = colv[r] * inv;
+    }
+    const float trow = li == C ? -inv : t;
+    P[RC] = lh == LC ? trow : P[RC];      // row C: P[C][j] / d, -1 / d on the diagonal
+    if constexpr (C + 1 < 32) sweep_step<C + 1>(P, li, lh);
+}
+
+// sum over the 32 lanes of each half-wave, returned in every lane of the half
+__device__ __forceinline__ float half_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v + __shfl_xor(v, 16, 64);
+}
+
+template <int T32>
+__global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const int32_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices, float *__restrict__ X,
+                                                           const float *__restrict__ Y, const float *__restrict__ A0,
+                                                           float weight, int32_t long_threshold) {
+    constexpr int K = 32 * T32;
+    constexpr int NT = T32 * (T32 + 1) / 2;
+    const int lane = threadIdx.x;
+    const int li = lane & 31, lh = lane >> 5;
+    for (int32_t i = blockIdx.x; i < rows; i += gridDim.x) {
+        const int32_t p0 = indptr[i], p1 = indptr[i + 1];
+        if (p0 == p1) {                                        // wmf.pyx:154-156
+#pragma unroll
+            for (int m = 0; m < T32; ++m) X[(int64_t)i * K + 32 * m + li] = 0.0f;
+            continue;
+        }
+        if (long_threshold > 0 && p1 - p0 > long_threshold) continue;   // built from segments
+        // T = A0 / (w - 1) + G: the system scaled by 1 / (w - 1), b scaled with it
+        f32x16 acc[NT];
+        float bsum[T32];
+        const float inv_w1 = 1.0f / (weight - 1.0f);
+#pragma unroll
+        for (int m = 0; m < T32; ++m) bsum[m] = 0.0f;
+        {
+            int a0off = 4 * lh * K + li;
+            asm volatile("" : "+v"(a0off));
+            const float *a0l = A0 + a0off;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[t][r] = a0l[(32 * tile_m(t) + (r & 3) + 8 * (r >> 2)) * K + 32 * tile_n(t)] * inv_w1;
+        }
+        for (int32_t pb = p0; pb < p1; pb += 64) {
+            const int32_t myp = pb + lane;
+            const int32_t myidx = myp < p1 ? indices[myp] : -1;
+            const int nb = p1 - pb < 64 ? p1 - pb : 64;
+            const int steps = (nb + 1) >> 1;
+            for (int s0 = 0; s0 < steps; s0 += 8) {
+                float ch[8][T32];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int32_t idx = __shfl(myidx, 2 * (s0 + u) + lh, 64);
+                    const bool ok = idx >= 0;
+                    const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
+#pragma unroll
+                    for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (s0 + u < steps) {                       // (uniform)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
+                    }
+                }
+            }
+        }
+        float bl[T32], z[T32];                                  // b_m and z_m, element j in lanes j and j + 32
+#pragma unroll
+        for (int m = 0; m < T32; ++m) bl[m] = (bsum[m] + __shfl_xor(bsum[m], 32, 64)) * (weight * inv_w1);
+#pragma unroll
+        for (int p = 0; p < T32; ++p) {
+            f32x16 &P = acc[blk_tix(p, p)];
+            sweep_step<0>(P, li, lh);                           // P <- -P^-1
+            float bp[16];                                       // b_p[k(r, lh)]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bp[r] = __shfl(bl[p], (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
+            float part = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part = __builtin_fmaf(P[r], bp[r], part);
+            z[p] = -(part + __shfl_xor(part, 32, 64));
+#pragma unroll
+            for (int n = T32 - 1; n > p; --n) {                 // descending: T(p,m), m <= n, are still the originals
+                f32x16 R = (f32x16)(0.0f);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) R = __builtin_amdgcn_mfma_f32_32x32x2f32(P[r], acc[blk_tix(p, n)][r], R, 0, 0, 0);
+#pragma unroll
+                for (int m = p + 1; m <= n; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[blk_tix(m, n)] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[blk_tix(p, m)][r], R[r], acc[blk_tix(m, n)], 0, 0, 0);
+                float pn = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pn = __builtin_fmaf(R[r], bp[r], pn);
+                bl[n] += pn + __shfl_xor(pn, 32, 64);
+                acc[blk_tix(p, n)] = R;
+            }
+        }
+        float x[T32];
+        x[T32 - 1] = z[T32 - 1];
+        const int rj = (li & 3) + 4 * (li >> 3), lj = (li >> 2) & 1;   // where row li of a tile lives
+#pragma unroll
+        for (int p = T32 - 2; p >= 0; --p) {
+            float sel = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sr = 0.0f;
+#pragma unroll
+                for (int n = p + 1; n < T32; ++n) sr = __builtin_fmaf(acc[blk_tix(p, n)][r], x[n], sr);
+                sr = half_sum(sr);                              // (R(p,.) x)[k(r, lh)], in every lane of the half
+                sel = r == rj ? sr : sel;
+            }
+            const float other = __shfl_xor(sel, 32, 64);
+            x[p] = z[p] + (lh == lj ? sel : other);
+        }
+        if (lh == 0) {
+#pragma unroll
+            for (int m = 0; m < T32; ++m) X[(int64_t)i * K + 32 * m + li] = x[m];   // wmf.pyx:170-171
+        }
     }
 }
 
@@ -773,6 +995,8 @@ struct cymf_wmf {
     int shard_rank = 0, shard_world = 1;   // from comm; CYMF_WMF_FAKE_SHARD="r/w" (tests) sets them without a communicator: no gather
     std::vector<int64_t> bounds[2];   // [world + 1] row boundaries per side (empty = single GPU)
     int probe = 0;           // CYMF_WMF_PROBE: 1 skips the solve, 2 the Gramian (timing only, results invalid)
+    int blocked = -1;        // CYMF_WMF_BLOCKED: 1/0 force/forbid the blocked elimination (wmf_row_blk_kernel); default: K >= 96
+    int prefetch = 0;        // CYMF_WMF_PREFETCH: look-ahead loads in the row kernel (one wave per SIMD less resident)
     bool reg_solve = true;   // register-resident solve (wmf_row_reg_kernel); CYMF_WMF_LDS_SOLVE=1 selects the in-LDS one
     // rows with more than long_threshold entries are built from segments (MFMA path)
     int32_t long_threshold = 2048;
@@ -881,13 +1105,23 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, my_rows, \
                                ip, ix, Xf, Yf, Gf, (float)h->weight, h->long_threshold, segs, nseg, h->d_scratch.p);        \
         if (my_rows <= 0) {                                                                                                 \
+        } else if (h->reg_solve && h->weight != 1.0 && (h->blocked >= 0 ? h->blocked != 0 : (T32_) >= 3)) {                 \
+            const int grid_b = (int)std::min<int64_t>(my_rows, 256 * 64);                                                   \
+            hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), 0, h->stream, my_rows, ip, ix, Xf, Yf, Gf, \
+                               (float)h->weight, nlong > 0 ? h->long_threshold : 0);                                        \
         } else if (h->reg_solve && h->weight != 1.0) {                                                                      \
             constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                        \
             const size_t smem_r = wmf_reg_smem<T32_, NW_>();                                                                \
-            CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_>, smem_r));                                                     \
             const int grid_r = (int)std::min<int64_t>(my_rows, 256 * 64);                                                   \
-            hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream, my_rows, ip, \
-                               ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe);              \
+            if (h->prefetch) {                                                                                              \
+                CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_, true>, smem_r));                                           \
+                hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_, true>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,   \
+                                   my_rows, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe); \
+            } else {                                                                                                        \
+                CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_, false>, smem_r));                                          \
+                hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_, false>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,  \
+                                   my_rows, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe); \
+            }                                                                                                               \
         } else {                                                                                                            \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, false>), dim3(grid), dim3(WMF_THREADS), smem, h->stream, my_rows, ip, \
                                ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, segs, nseg, h->d_scratch.p); \
@@ -954,6 +1188,8 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     const char *env = getenv("CYMF_WMF_NO_MFMA");
     h->use_mfma = !(env && env[0] == '1');
     if (const char *e4 = getenv("CYMF_WMF_PROBE")) h->probe = atoi(e4);
+    if (const char *e6 = getenv("CYMF_WMF_PREFETCH")) h->prefetch = atoi(e6);
+    if (const char *e7 = getenv("CYMF_WMF_BLOCKED")) h->blocked = atoi(e7);
     if (const char *e5 = getenv("CYMF_WMF_FAKE_SHARD")) {
         int r = 0, w = 1;
         if (sscanf(e5, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) { h->shard_rank = r; h->shard_world = w; }
