@@ -533,7 +533,8 @@ template <int T32, int NW, bool PRE>
 __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wmf_row_reg_kernel(int32_t rows, const int32_t *__restrict__ indptr,
                                                              const int32_t *__restrict__ indices, float *__restrict__ X,
                                                              const float *__restrict__ Y, const float *__restrict__ A0,
-                                                             float weight, int32_t long_threshold, int probe) {
+                                                             float weight, int32_t long_threshold, int probe,
+                                                             const int32_t *__restrict__ order) {
     constexpr int K = 32 * T32;
     constexpr int NT = T32 * (T32 + 1) / 2;
     extern __shared__ unsigned char smem_raw[];
@@ -544,7 +545,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wm
     const int tid = threadIdx.x, lane = tid & 63, wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
 
-    for (int32_t i = blockIdx.x; i < rows; i += gridDim.x) {
+    for (int32_t wi = blockIdx.x; wi < rows; wi += gridDim.x) {
+        const int32_t i = order ? order[wi] : wi;                // work item wi: the wi-th longest row
         const int32_t p0 = indptr[i];
         int32_t p1 = indptr[i + 1];
         int j = tid;
@@ -692,30 +694,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wm
 // SIMD: one wave's sweep (a chain of ds_bpermute round trips) runs under the other's MFMAs.
 constexpr int blk_tix(int m, int n) { return n * (n + 1) / 2 + m; }   // = the order of tile_m / tile_n
 
+// Sweep of pivot C of a symmetric 32 x 32 tile in the C layout: P[i][j] -= P[i][C] P[C][j] / d, row and column C <- themselves / d,
+// P[C][C] <- -1 / d (after all 32 pivots: P = -P^-1).  The rank-1 update is ONE v_mfma_f32_32x32x2_f32: row C lies in register
+// RC of the lanes of half LC, element j in lane j -- which is exactly the operand layout (lane l supplies A[l & 31][l >> 5] and
+// B[l >> 5][l & 31]); with the other half's operands zero, A = -row / d and B = row, the product is the outer product.  P[i][C]
+// is taken as P[C][i]: the tile is symmetric up to rounding.  (The first version fetched column C with 16 ds_bpermute per
+// pivot and updated with v_pk_fma_f32: 8 waves x 17 permutes per pivot saturated the CU's LDS pipe, 1.3 k cycles per pivot.)
 template <int C>
 __device__ __forceinline__ void sweep_step(f32x16 &P, int li, int lh) {
-    constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;     // row C: register RC of the lanes of half LC
-    const float rowv = __shfl(P[RC], li + 32 * LC, 64);               // P[C][j] for this lane's column j
-    float colv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) colv[r] = __shfl(P[r], C + 32 * lh, 64);   // P[k(r, lh)][C]
-    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rowv), C));
+    constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;
+    const float prow = P[RC];
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prow), C + 32 * LC));
     const float inv = rcp_nr(d);
-    const float t = rowv * inv;
-    const f32x2 nt2 = {-t, -t};
+    const bool mine = lh == LC;
+    const float bop = mine ? prow : 0.0f;
+    const float aop = -inv * bop;
+    f32x16 Q = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, P, 0, 0, 0);
+    if (li == C) {                        // column C (lane C of both halves): the old entries / d
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        f32x2 v = {P[2 * g], P[2 * g + 1]};
-        v = __builtin_elementwise_fma(f32x2{colv[2 * g], colv[2 * g + 1]}, nt2, v);
-        P[2 * g] = v[0];
-        P[2 * g + 1] = v[1];
+        for (int r = 0; r < 16; ++r) Q[r] = P[r] * inv;
     }
-    if (li == C) {                        // column C: P[i][C] / d (the generic update left exact zeros here)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) P[r] = colv[r] * inv;
-    }
-    const float trow = li == C ? -inv : t;
-    P[RC] = lh == LC ? trow : P[RC];      // row C: P[C][j] / d, -1 / d on the diagonal
+    Q[RC] = mine ? (li == C ? -inv : prow * inv) : Q[RC];   // row C: P[C][j] / d, -1 / d on the diagonal
+    P = Q;
     if constexpr (C + 1 < 32) sweep_step<C + 1>(P, li, lh);
 }
 
@@ -732,19 +732,28 @@ template <int T32>
 __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const int32_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices, float *__restrict__ X,
                                                            const float *__restrict__ Y, const float *__restrict__ A0,
-                                                           float weight, int32_t long_threshold) {
+                                                           float weight, int32_t long_threshold, int probe,
+                                                           const int32_t *__restrict__ order) {
     constexpr int K = 32 * T32;
     constexpr int NT = T32 * (T32 + 1) / 2;
-    const int lane = threadIdx.x;
-    const int li = lane & 31, lh = lane >> 5;
-    for (int32_t i = blockIdx.x; i < rows; i += gridDim.x) {
-        const int32_t p0 = indptr[i], p1 = indptr[i + 1];
+    constexpr int GS = T32 >= 4 ? 4 : 8;
+    for (int32_t wi = blockIdx.x; wi < rows; wi += gridDim.x) {
+        const int32_t i = order ? order[wi] : wi;                // work item wi: the wi-th longest row
+        // the lane number is made opaque per row and again per phase: everything derived from it (permute index vectors, tile
+        // corner offsets, the 32 pivot-lane masks of a sweep) would otherwise be hoisted out of the row loop and held in
+        // registers across all phases (108 VGPRs at K=32, 970 bytes of scratch per lane at K=128)
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+        int li = lane & 31, lh = lane >> 5;
+        const int32_t p0 = indptr[i];
+        int32_t p1 = indptr[i + 1];
         if (p0 == p1) {                                        // wmf.pyx:154-156
 #pragma unroll
             for (int m = 0; m < T32; ++m) X[(int64_t)i * K + 32 * m + li] = 0.0f;
             continue;
         }
         if (long_threshold > 0 && p1 - p0 > long_threshold) continue;   // built from segments
+        if (probe == 2) p1 = p0;                                         // timing probe: no gather, no Gramian
         // T = A0 / (w - 1) + G: the system scaled by 1 / (w - 1), b scaled with it
         f32x16 acc[NT];
         float bsum[T32];
@@ -761,23 +770,33 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
                 for (int r = 0; r < 16; ++r)
                     acc[t][r] = a0l[(32 * tile_m(t) + (r & 3) + 8 * (r >> 2)) * K + 32 * tile_n(t)] * inv_w1;
         }
+        // 64 gathered rows per batch (lane l holds the index of entry l), GS k=2 steps per group (8; 4 at K=128, where the 160
+        // accumulator registers leave no room for 32 operands: the compiler then spills a whole tile and reloads it around
+        // every step, 3500 cycles per step instead of 1280): each of the T32 32-column chunks
+        // of a gathered row is loaded once per step and feeds every tile that uses it.  One 32-bit byte offset per gathered row,
+        // the chunk offsets are immediates (the host sends tables beyond 4 GB to the other kernel); the loads are unconditional
+        // -- entry 0 of the table stands in for a missing row -- and selected after.
+        const char *Yb = reinterpret_cast<const char *>(Y);
         for (int32_t pb = p0; pb < p1; pb += 64) {
             const int32_t myp = pb + lane;
             const int32_t myidx = myp < p1 ? indices[myp] : -1;
             const int nb = p1 - pb < 64 ? p1 - pb : 64;
             const int steps = (nb + 1) >> 1;
-            for (int s0 = 0; s0 < steps; s0 += 8) {
-                float ch[8][T32];
+            for (int s0 = 0; s0 < steps; s0 += GS) {
+                float ch[GS][T32];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < GS; ++u) {
                     const int32_t idx = __shfl(myidx, 2 * (s0 + u) + lh, 64);
                     const bool ok = idx >= 0;
-                    const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
+                    const uint32_t off = (uint32_t)(ok ? idx : 0) * (uint32_t)(K * 4) + (uint32_t)(li * 4);
 #pragma unroll
-                    for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
+                    for (int m = 0; m < T32; ++m) {
+                        const float v = *reinterpret_cast<const float *>(Yb + off + 128 * m);
+                        ch[u][m] = ok ? v : 0.0f;
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < GS; ++u) {
                     if (s0 + u < steps) {                       // (uniform)
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
@@ -788,9 +807,22 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
                 }
             }
         }
+        asm volatile("" : "+v"(lane));
+        li = lane & 31;
+        lh = lane >> 5;
         float bl[T32], z[T32];                                  // b_m and z_m, element j in lanes j and j + 32
 #pragma unroll
         for (int m = 0; m < T32; ++m) bl[m] = (bsum[m] + __shfl_xor(bsum[m], 32, 64)) * (weight * inv_w1);
+        if (probe == 1) {                                       // timing probe: no elimination
+            float sacc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[t][r];
+            const float out = sacc + bl[0];
+            if (lh == 0) X[(int64_t)i * K + li] = out;
+            continue;
+        }
 #pragma unroll
         for (int p = 0; p < T32; ++p) {
             f32x16 &P = acc[blk_tix(p, p)];
@@ -995,6 +1027,7 @@ struct cymf_wmf {
     int shard_rank = 0, shard_world = 1;   // from comm; CYMF_WMF_FAKE_SHARD="r/w" (tests) sets them without a communicator: no gather
     std::vector<int64_t> bounds[2];   // [world + 1] row boundaries per side (empty = single GPU)
     int probe = 0;           // CYMF_WMF_PROBE: 1 skips the solve, 2 the Gramian (timing only, results invalid)
+    int row_order = 1;       // CYMF_WMF_ROW_ORDER=0: rows in index order instead of longest first
     int blocked = -1;        // CYMF_WMF_BLOCKED: 1/0 force/forbid the blocked elimination (wmf_row_blk_kernel); default: K >= 96
     int prefetch = 0;        // CYMF_WMF_PREFETCH: look-ahead loads in the row kernel (one wave per SIMD less resident)
     bool reg_solve = true;   // register-resident solve (wmf_row_reg_kernel); CYMF_WMF_LDS_SOLVE=1 selects the in-LDS one
@@ -1003,6 +1036,8 @@ struct cymf_wmf {
     int32_t seg_len = 0;            // 0: default (see set_data); CYMF_WMF_SEG
     DevBuf<cymf::WmfSeg> d_segs[2];
     DevBuf<int32_t> d_long_rows[2];
+    DevBuf<int32_t> d_order[2];     // this rank's whole rows (offsets from its first row), longest first: the row kernels' work list
+    int32_t n_order[2] = {0, 0};
     int32_t n_segs[2] = {0, 0}, n_long[2] = {0, 0};
     DevBuf<float> d_scratch;
     // YtY on the MFMA path: identity index list and segments over the rows of each table (0 = W, 1 = H)
@@ -1094,6 +1129,9 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             const WmfSeg *segs = h->d_segs[side].p;
             if (nlong > 0) CYMF_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)nlong * ((size_t)K * K + K) * sizeof(float), h->stream));
             const int grid_seg = (int)std::min<int64_t>(nseg, 256 * 16);
+            const bool sorted = h->row_order && h->d_order[side].p;
+            const int32_t *order = sorted ? h->d_order[side].p : nullptr;
+            const int32_t n_work = sorted ? h->n_order[side] : my_rows;
 #define WMF_LAUNCH_(T32_)                                                                                                   \
     do {                                                                                                                    \
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, false>, smem));                                                        \
@@ -1106,21 +1144,21 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
                                ip, ix, Xf, Yf, Gf, (float)h->weight, h->long_threshold, segs, nseg, h->d_scratch.p);        \
         if (my_rows <= 0) {                                                                                                 \
         } else if (h->reg_solve && h->weight != 1.0 && (h->blocked >= 0 ? h->blocked != 0 : (T32_) >= 3)) {                 \
-            const int grid_b = (int)std::min<int64_t>(my_rows, 256 * 64);                                                   \
-            hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), 0, h->stream, my_rows, ip, ix, Xf, Yf, Gf, \
-                               (float)h->weight, nlong > 0 ? h->long_threshold : 0);                                        \
+            const int grid_b = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
+            hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), 0, h->stream, n_work, ip, ix, Xf, Yf, Gf, \
+                               (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order);                       \
         } else if (h->reg_solve && h->weight != 1.0) {                                                                      \
             constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                        \
             const size_t smem_r = wmf_reg_smem<T32_, NW_>();                                                                \
-            const int grid_r = (int)std::min<int64_t>(my_rows, 256 * 64);                                                   \
+            const int grid_r = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
             if (h->prefetch) {                                                                                              \
                 CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_, true>, smem_r));                                           \
                 hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_, true>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,   \
-                                   my_rows, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe); \
+                                   n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order); \
             } else {                                                                                                        \
                 CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_, false>, smem_r));                                          \
                 hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_, false>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,  \
-                                   my_rows, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe); \
+                                   n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order); \
             }                                                                                                               \
         } else {                                                                                                            \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, false>), dim3(grid), dim3(WMF_THREADS), smem, h->stream, my_rows, ip, \
@@ -1190,6 +1228,7 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     if (const char *e4 = getenv("CYMF_WMF_PROBE")) h->probe = atoi(e4);
     if (const char *e6 = getenv("CYMF_WMF_PREFETCH")) h->prefetch = atoi(e6);
     if (const char *e7 = getenv("CYMF_WMF_BLOCKED")) h->blocked = atoi(e7);
+    if (const char *e8 = getenv("CYMF_WMF_ROW_ORDER")) h->row_order = atoi(e8);
     if (const char *e5 = getenv("CYMF_WMF_FAKE_SHARD")) {
         int r = 0, w = 1;
         if (sscanf(e5, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) { h->shard_rank = r; h->shard_world = w; }
@@ -1275,6 +1314,18 @@ extern "C" int cymf_wmf_set_data(cymf_wmf *h, const int32_t *indptr, const int32
             for (int32_t b = ip[r]; b < ip[r + 1]; b += seg_len)
                 segs.push_back(WmfSeg{slot, b, std::min(b + seg_len, ip[r + 1]), 0});
         }
+        // Work list of the whole-row kernels: longest row first.  Row lengths follow a power law (C4 users: mean 144, 1 % above
+        // 736, up to the threshold), and with rows dealt out in index order the sweep ended when the unluckiest workgroup did:
+        // +33 % over the mean on C4 (greedy schedule of the measured lengths).  Longest-first is the classic LPT rule.
+        std::vector<int32_t> order;
+        order.reserve((size_t)(r_hi - r_lo));
+        for (int32_t r = r_lo; r < r_hi; ++r)
+            if (ip[r + 1] - ip[r] <= h->long_threshold) order.push_back(r - r_lo);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return ip[r_lo + a + 1] - ip[r_lo + a] > ip[r_lo + b + 1] - ip[r_lo + b];
+        });
+        h->n_order[side] = (int32_t)order.size();
+        CYMF_TRY(h->d_order[side].upload(order.data(), order.size(), h->stream));
         h->n_segs[side] = (int32_t)segs.size();
         h->n_long[side] = (int32_t)longs.size();
         CYMF_TRY(h->d_segs[side].upload(segs.data(), segs.size(), h->stream));

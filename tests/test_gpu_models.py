@@ -290,7 +290,8 @@ def test_wmf_register_and_lds_solvers_agree(K, monkeypatch):
         m = WMF(K, 0.01, 10.0)
         m.fit(X, num_epochs=2, verbose=False, dtype="float32")
         out.append((m.W.copy(), m.H.copy()))
-    assert _close(out[0][0], out[1][0], 1e-4) and _close(out[0][1], out[1][1], 1e-4)   # both sit ~1e-5 from the f64 oracle at K=128
+    tol = 1e-4 if K <= 64 else 2e-4   # K >= 96: blocked elimination vs Cholesky; tools/wmf_accuracy.py prices both against the f64 oracle
+    assert _close(out[0][0], out[1][0], tol) and _close(out[0][1], out[1][1], tol)
     assert (out[0][0][3] == 0).all()
 
 
