@@ -679,44 +679,151 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wm
 }
 
 // ---------------------------------------------------------------------------------------------
-// Blocked elimination in the MFMA accumulator layout (K = 96, 128): ONE wavefront per row, no LDS, no layout change.
+// Blocked Cholesky in the MFMA accumulator layout (K = 96, 128): ONE wavefront per row, no LDS, no layout change.
 // The system stays where the Gramian was accumulated -- upper-triangular 32 x 32 tiles T(m, n), m <= n, in the C/D layout of
-// v_mfma_f32_32x32x2_f32 (lane l: column l & 31; register r: row (r & 3) + 8 (r >> 2) + 4 (l >> 5)) -- and is eliminated panel
-// by panel (block Gaussian elimination of an SPD matrix, no pivoting):
-//     N      = -T(p,p)^-1                       32 x 32 symmetric sweep, VALU + ds_bpermute (sweep_step)
-//     R(p,n) = N T(p,n)                         16 MFMAs per tile: register r of N is the A operand (N is symmetric, so its
-//                                               C-layout register holds N[i][k] for lane i and this half's k), register r of
-//                                               T(p,n) the B operand -- VGPR operands as they lie, no broadcast through LDS
-//     T(m,n) += T(p,m)^T R(p,n),  p < m <= n    16 MFMAs per tile, operands again registers r of T(p,m) and R(p,n)
-//     b_n    += R(p,n)^T b_p,  z_p = -N b_p     16 FMAs per tile and lane
-// and x_p = z_p + sum_{n > p} R(p,n) x_n on the way back.  Per K=128 row: 256 MFMAs for the factorisation (the register
-// Gauss-Jordan above spends 2 x 8192 v_pk_fma_f32 and a 128-step latency chain on two waves), and two independent waves per
-// SIMD: one wave's sweep (a chain of ds_bpermute round trips) runs under the other's MFMAs.
+// v_mfma_f32_32x32x2_f32 (lane l: column l & 31; register r: row (r & 3) + 8 (r >> 2) + 4 (l >> 5)) -- and is factored
+// block row by block row, A = U^T U (SPD, no pivoting):
+//     block row p, 32 steps   row c of every tile T(p, n >= p) is scaled and subtracted from the rows below it: one rank-1
+//                             MFMA per tile and step (chol_step); afterwards T(p,p) = U_pp, T(p,n) = S(p,n) = U_pp^-T T(p,n)
+//     T(m,n) -= S(p,m)^T S(p,n), p < m <= n   16 MFMAs per tile: registers r of S(p,m) and S(p,n) ARE the A and B operands
+//                             (lane i of register r holds S[k][i], k this half's row of the pair) -- VGPR operands as they
+//                             lie, no broadcast through LDS
+//     y = U^-T b rides along in lane layout; x_p = U_pp^-1 (y_p - sum_{n>p} S(p,n) x_n) on the way back, with U_pp transposed
+//     through the matrix unit so that its columns come in lane layout too (back_step).
+// Per K=128 row: 320 + 160 + 64 MFMAs (the register Gauss-Jordan above spends 2 x 8192 v_pk_fma_f32 and a 128-step latency
+// chain on two waves), and two independent waves per SIMD.  History: the first blocked version eliminated with explicit
+// inverses of the 32 x 32 pivot blocks (symmetric sweep, R = -P^-1 T): 256 + 128 MFMAs, but 5-6 x the error of the
+// Gauss-Jordan on lambda-dominated systems (tools/wmf_accuracy.py: 1.1e-4 against 1.9e-5 relative to the f64 oracle at K=128)
+// -- products with P^-1 carry cond(P), products with U^-1 its square root.
 constexpr int blk_tix(int m, int n) { return n * (n + 1) / 2 + m; }   // = the order of tile_m / tile_n
 
-// Sweep of pivot C of a symmetric 32 x 32 tile in the C layout: P[i][j] -= P[i][C] P[C][j] / d, row and column C <- themselves / d,
-// P[C][C] <- -1 / d (after all 32 pivots: P = -P^-1).  The rank-1 update is ONE v_mfma_f32_32x32x2_f32: row C lies in register
-// RC of the lanes of half LC, element j in lane j -- which is exactly the operand layout (lane l supplies A[l & 31][l >> 5] and
-// B[l >> 5][l & 31]); with the other half's operands zero, A = -row / d and B = row, the product is the outer product.  P[i][C]
-// is taken as P[C][i]: the tile is symmetric up to rounding.  (The first version fetched column C with 16 ds_bpermute per
-// pivot and updated with v_pk_fma_f32: 8 waves x 17 permutes per pivot saturated the CU's LDS pipe, 1.3 k cycles per pivot.)
-template <int C>
-__device__ __forceinline__ void sweep_step(f32x16 &P, int li, int lh) {
+// A0 / (w - 1) re-laid for wmf_row_blk_kernel: tile t, lane l, register r at [(t * 64 + l) * 16 + r], so that a row's 16 starting
+// values per tile are four 16-byte loads (160 scalar loads and multiplies per row otherwise; the matrix is 64 KB, L2-resident).
+template <int T32>
+__global__ void wmf_tile_layout_kernel(const float *__restrict__ A0, float inv_w1, float *__restrict__ out) {
+    constexpr int K = 32 * T32, NT = T32 * (T32 + 1) / 2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NT * 64 * 16) return;
+    const int r = e & 15, l = (e >> 4) & 63, t = e >> 10;
+    int m = 0, n = 0;
+    for (int q = 0; q < NT; ++q)
+        if (q == t) { m = tile_m(q); n = tile_n(q); }
+    const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = 32 * n + (l & 31);
+    out[e] = A0[row * K + col] * inv_w1;
+}
+
+// Cross-half moves without the LDS pipe (gfx950): v_permlane32_swap exchanges the upper half of one register with the lower
+// half of another, so swapping a value with a copy of itself yields {its lower half in both halves, its upper half in both
+// halves}; v_permlane16_swap does the same for the odd / even rows of 16 lanes.  Inline assembly on purpose: a swap issued
+// directly after the VALU instruction that wrote its operand reads stale lanes, and hipcc 7.2 inserts no wait state
+// (tools/micro/permlane.hip: half-wave sums off by one row; one s_nop 0 in front is enough for both).
+__device__ __forceinline__ void swap32_self(float v, float &lo_all, float &hi_all) {
+    asm("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\tv_permlane32_swap_b32 %0, %1" : "=&v"(lo_all), "=&v"(hi_all) : "v"(v));
+}
+__device__ __forceinline__ float half_bcast(float v, int half) {   // lanes l and l + 32 <- v of lane l + 32 * half
+    float lo, hi;
+    swap32_self(v, lo, hi);
+    return half ? hi : lo;
+}
+__device__ __forceinline__ float other_half(float v, int lh) {     // v of lane l ^ 32
+    float lo, hi;
+    swap32_self(v, lo, hi);
+    return lh ? lo : hi;
+}
+
+__device__ __forceinline__ float rsq_nr(float d) {   // v_rsq_f32 + one Newton step
+    const float y = __builtin_amdgcn_rsqf(d);
+    return y * (1.5f - 0.5f * d * y * y);
+}
+__device__ __forceinline__ float lane_value(float v, int l) {   // v_readlane_b32
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// Step C of the Cholesky factorisation of block row P (upper factor, A = U^T U) in the C layout.  Row C of a tile lies in
+// register RC of the lanes of half LC, element j in lane j -- which is exactly the operand layout of v_mfma_f32_32x32x2_f32
+// (lane l supplies A[l & 31][l >> 5] and B[l >> 5][l & 31]); with the other half's operands zero, one MFMA per tile is the
+// rank-1 update of the step:  row C <- row C / sqrt(d)  (= row C of U and of S(P,n) = U^-T T(P,n)),  rows i > C of every tile
+// of the block row -= U[C][i] * (row C).  U[C][i] is taken from row C of the diagonal tile: the tile is symmetric up to
+// rounding.  Rows <= C are not touched (A operand masked); what the updates write below the diagonal of the diagonal tile is
+// never read.  The right-hand side rides along (forward substitution, lane layout): only the copy in half LC is current, the
+// halves are synchronised every fourth step (rows C..C+3 share a half).
+template <int T32, int P, int C>
+__device__ __forceinline__ void chol_step(f32x16 (&acc)[T32 * (T32 + 1) / 2], float &bcur, float &ycur, float &rsd, int li, int lh) {
     constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;
-    const float prow = P[RC];
-    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, prow), C + 32 * LC));
-    const float inv = rcp_nr(d);
+    f32x16 &D = acc[blk_tix(P, P)];
     const bool mine = lh == LC;
-    const float bop = mine ? prow : 0.0f;
-    const float aop = -inv * bop;
-    f32x16 Q = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, bop, P, 0, 0, 0);
-    if (li == C) {                        // column C (lane C of both halves): the old entries / d
+    const float prow = D[RC];
+    const float rs = rsq_nr(lane_value(prow, C + 32 * LC));
+    const float urow = prow * rs;
+    D[RC] = mine ? urow : prow;
+    const float aop = mine && li > C ? -urow : 0.0f;
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, mine ? urow : 0.0f, D, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Q[r] = P[r] * inv;
+    for (int n = P + 1; n < T32; ++n) {
+        f32x16 &S = acc[blk_tix(P, n)];
+        const float srow = S[RC] * rs;
+        S[RC] = mine ? srow : S[RC];
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, mine ? srow : 0.0f, S, 0, 0, 0);
     }
-    Q[RC] = mine ? (li == C ? -inv : prow * inv) : Q[RC];   // row C: P[C][j] / d, -1 / d on the diagonal
-    P = Q;
-    if constexpr (C + 1 < 32) sweep_step<C + 1>(P, li, lh);
+    const float yc = lane_value(bcur, C + 32 * LC) * rs;
+    ycur = li == C ? yc : ycur;
+    rsd = li == C ? rs : rsd;
+    // pinned: left alone, the compiler keeps the 32 (yc, rs) pairs of a block row alive and builds the two vectors where they
+    // are first read -- 64 registers per block row, paid for with accumulator tiles in scratch
+    asm volatile("" : "+v"(ycur), "+v"(rsd));
+    bcur = __builtin_fmaf(aop, yc, bcur);
+    if constexpr ((C & 3) == 3 && C + 1 < 32) bcur = half_bcast(bcur, LC);
+    if constexpr (C + 1 < 32) chol_step<T32, P, C + 1>(acc, bcur, ycur, rsd, li, lh);
+}
+
+// Step C (descending) of x = U^-1 w with the transposed tile L = U^T in the C layout: row C of L is column C of U, in lane layout.
+template <int C>
+__device__ __forceinline__ void back_step(const f32x16 &L, float &w, float &x, float rsd, int li, int lh) {
+    constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;
+    const bool mine = lh == LC;
+    const float xc = lane_value(w, C + 32 * LC) * lane_value(rsd, C);
+    x = li == C ? xc : x;
+    asm volatile("" : "+v"(x));
+    w = __builtin_fmaf(mine && li < C ? -L[RC] : 0.0f, xc, w);
+    if constexpr ((C & 3) == 0 && C > 0) w = half_bcast(w, LC);
+    if constexpr (C > 0) back_step<C - 1>(L, w, x, rsd, li, lh);
+}
+
+template <int T32, int P>
+__device__ __forceinline__ void chol_panels(f32x16 (&acc)[T32 * (T32 + 1) / 2], float (&bl)[T32], float (&y)[T32], float (&rsd)[T32], int li, int lh) {
+    y[P] = 0.0f;
+    rsd[P] = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+    chol_step<T32, P, 0>(acc, bl[P], y[P], rsd[P], li, lh);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (P + 1 < T32) {
+        // T(m,n) -= S(P,m)^T S(P,n), P < m <= n: registers r of S(P,m) and of S(P,n) are the operands as they lie.  The tiles
+        // of the later block rows are kept NEGATED until their own block row is factored (the kernel negates them once after
+        // the Gramian, the block row is negated back below): the update is then an addition and needs no negated copy of
+        // S(P,m) -- a 16-register temporary per m that, with the register file fragmented by 160 accumulator registers,
+        // made the compiler spill whole tiles.
+#pragma unroll
+        for (int m = P + 1; m < T32; ++m)
+#pragma unroll
+            for (int n = m; n < T32; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[blk_tix(m, n)] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[blk_tix(P, m)][r], acc[blk_tix(P, n)][r], acc[blk_tix(m, n)], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        float yreg[16];                                         // y_P[k(r, lh)]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yreg[r] = __shfl(y[P], (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
+#pragma unroll
+        for (int m = P + 1; m < T32; ++m) {
+            float part = 0.0f;                                  // b_m -= S(P,m)^T y_P
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part = __builtin_fmaf(acc[blk_tix(P, m)][r], yreg[r], part);
+            bl[m] -= part + other_half(part, lh);
+        }
+#pragma unroll
+        for (int n = P + 1; n < T32; ++n) acc[blk_tix(P + 1, n)] = -acc[blk_tix(P + 1, n)];   // block row P + 1 comes next
+        chol_panels<T32, P + 1>(acc, bl, y, rsd, li, lh);
+    }
 }
 
 // sum over the 32 lanes of each half-wave, returned in every lane of the half
@@ -725,7 +832,9 @@ __device__ __forceinline__ float half_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
-    return v + __shfl_xor(v, 16, 64);
+    float even, odd;   // {rows 0 0 2 2, rows 1 1 3 3}
+    asm("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\tv_permlane16_swap_b32 %0, %1" : "=&v"(even), "=&v"(odd) : "v"(v));
+    return even + odd;
 }
 
 template <int T32>
@@ -733,12 +842,14 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
                                                            const int32_t *__restrict__ indices, float *__restrict__ X,
                                                            const float *__restrict__ Y, const float *__restrict__ A0,
                                                            float weight, int32_t long_threshold, int probe,
-                                                           const int32_t *__restrict__ order) {
+                                                           const int32_t *__restrict__ order, unsigned long long *__restrict__ phase_ticks) {
     constexpr int K = 32 * T32;
     constexpr int NT = T32 * (T32 + 1) / 2;
     constexpr int GS = T32 >= 4 ? 4 : 8;
     for (int32_t wi = blockIdx.x; wi < rows; wi += gridDim.x) {
         const int32_t i = order ? order[wi] : wi;                // work item wi: the wi-th longest row
+        unsigned long long tk[5] = {0, 0, 0, 0, 0};              // CYMF_WMF_PROBE=5: s_memtime at the phase boundaries (tools/wmf_probe.py)
+        if (probe == 5) tk[0] = __builtin_amdgcn_s_memtime();
         // the lane number is made opaque per row and again per phase: everything derived from it (permute index vectors, tile
         // corner offsets, the 32 pivot-lane masks of a sweep) would otherwise be hoisted out of the row loop and held in
         // registers across all phases (108 VGPRs at K=32, 970 bytes of scratch per lane at K=128)
@@ -761,14 +872,15 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
 #pragma unroll
         for (int m = 0; m < T32; ++m) bsum[m] = 0.0f;
         {
-            int a0off = 4 * lh * K + li;
-            asm volatile("" : "+v"(a0off));
-            const float *a0l = A0 + a0off;
+            using f4 = __attribute__((ext_vector_type(4))) float;
+            const f4 *a0t = reinterpret_cast<const f4 *>(A0) + lane * 4;   // A0: the tile layout of wmf_tile_layout_kernel
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[t][r] = a0l[(32 * tile_m(t) + (r & 3) + 8 * (r >> 2)) * K + 32 * tile_n(t)] * inv_w1;
+                for (int q = 0; q < 4; ++q) {
+                    const f4 v = a0t[t * 256 + q];
+                    acc[t][4 * q] = v[0]; acc[t][4 * q + 1] = v[1]; acc[t][4 * q + 2] = v[2]; acc[t][4 * q + 3] = v[3];
+                }
         }
         // 64 gathered rows per batch (lane l holds the index of entry l), GS k=2 steps per group (8; 4 at K=128, where the 160
         // accumulator registers leave no room for 32 operands: the compiler then spills a whole tile and reloads it around
@@ -777,6 +889,7 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
         // the chunk offsets are immediates (the host sends tables beyond 4 GB to the other kernel); the loads are unconditional
         // -- entry 0 of the table stands in for a missing row -- and selected after.
         const char *Yb = reinterpret_cast<const char *>(Y);
+        if (probe == 5) { asm volatile("" : "+v"(acc[NT - 1][15])); tk[1] = __builtin_amdgcn_s_memtime(); }
         for (int32_t pb = p0; pb < p1; pb += 64) {
             const int32_t myp = pb + lane;
             const int32_t myidx = myp < p1 ? indices[myp] : -1;
@@ -810,9 +923,10 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
         asm volatile("" : "+v"(lane));
         li = lane & 31;
         lh = lane >> 5;
-        float bl[T32], z[T32];                                  // b_m and z_m, element j in lanes j and j + 32
+        if (probe == 5) { asm volatile("" : "+v"(acc[0][0])); tk[2] = __builtin_amdgcn_s_memtime(); }
+        float bl[T32], y[T32], rsd[T32];                        // b_m, y_m = (U^-T b)_m, 1 / diag(U)_m: element j in lanes j and j + 32
 #pragma unroll
-        for (int m = 0; m < T32; ++m) bl[m] = (bsum[m] + __shfl_xor(bsum[m], 32, 64)) * (weight * inv_w1);
+        for (int m = 0; m < T32; ++m) bl[m] = (bsum[m] + other_half(bsum[m], lh)) * (weight * inv_w1);
         if (probe == 1) {                                       // timing probe: no elimination
             float sacc = 0.0f;
 #pragma unroll
@@ -824,53 +938,50 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
             continue;
         }
 #pragma unroll
-        for (int p = 0; p < T32; ++p) {
-            f32x16 &P = acc[blk_tix(p, p)];
-            sweep_step<0>(P, li, lh);                           // P <- -P^-1
-            float bp[16];                                       // b_p[k(r, lh)]
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bp[r] = __shfl(bl[p], (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
-            float part = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part = __builtin_fmaf(P[r], bp[r], part);
-            z[p] = -(part + __shfl_xor(part, 32, 64));
-#pragma unroll
-            for (int n = T32 - 1; n > p; --n) {                 // descending: T(p,m), m <= n, are still the originals
-                f32x16 R = (f32x16)(0.0f);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) R = __builtin_amdgcn_mfma_f32_32x32x2f32(P[r], acc[blk_tix(p, n)][r], R, 0, 0, 0);
-#pragma unroll
-                for (int m = p + 1; m <= n; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[blk_tix(m, n)] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[blk_tix(p, m)][r], R[r], acc[blk_tix(m, n)], 0, 0, 0);
-                float pn = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pn = __builtin_fmaf(R[r], bp[r], pn);
-                bl[n] += pn + __shfl_xor(pn, 32, 64);
-                acc[blk_tix(p, n)] = R;
-            }
-        }
+        for (int t = 0; t < NT; ++t)
+            if (tile_m(t) >= 1) acc[t] = -acc[t];              // (see chol_panels: later block rows are carried negated)
+        chol_panels<T32, 0>(acc, bl, y, rsd, li, lh);
+        if (probe == 5) { asm volatile("" : "+v"(y[T32 - 1])); tk[3] = __builtin_amdgcn_s_memtime(); }
+        // back substitution: x_p = U_pp^-1 (y_p - sum_{n > p} S(p,n) x_n)
         float x[T32];
-        x[T32 - 1] = z[T32 - 1];
         const int rj = (li & 3) + 4 * (li >> 3), lj = (li >> 2) & 1;   // where row li of a tile lives
 #pragma unroll
-        for (int p = T32 - 2; p >= 0; --p) {
-            float sel = 0.0f;
+        for (int p = T32 - 1; p >= 0; --p) {
+            __builtin_amdgcn_sched_barrier(0);
+            float w = y[p];
+            if (p + 1 < T32) {
+                float sel = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sr = 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    float sr = 0.0f;
 #pragma unroll
-                for (int n = p + 1; n < T32; ++n) sr = __builtin_fmaf(acc[blk_tix(p, n)][r], x[n], sr);
-                sr = half_sum(sr);                              // (R(p,.) x)[k(r, lh)], in every lane of the half
-                sel = r == rj ? sr : sel;
+                    for (int n = p + 1; n < T32; ++n) sr = __builtin_fmaf(acc[blk_tix(p, n)][r], x[n], sr);
+                    sr = half_sum(sr);                          // (S(p,.) x)[k(r, lh)], in every lane of the half
+                    sel = r == rj ? sr : sel;
+                }
+                const float other = other_half(sel, lh);
+                w -= lh == lj ? sel : other;
             }
-            const float other = __shfl_xor(sel, 32, 64);
-            x[p] = z[p] + (lh == lj ? sel : other);
+            // L = U_pp^T through the matrix unit (D[i][j] = sum_k U[k][i] I[k][j]): its rows are the columns of U in lane layout
+            f32x16 L = (f32x16)(0.0f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                L = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[blk_tix(p, p)][r], li == (r & 3) + 8 * (r >> 2) + 4 * lh ? 1.0f : 0.0f, L, 0, 0, 0);
+            x[p] = 0.0f;
+            back_step<31>(L, w, x[p], rsd[p], li, lh);
         }
         if (lh == 0) {
 #pragma unroll
             for (int m = 0; m < T32; ++m) X[(int64_t)i * K + 32 * m + li] = x[m];   // wmf.pyx:170-171
+        }
+        if (probe == 5) {
+            asm volatile("" : "+v"(x[0]));
+            tk[4] = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicAdd(phase_ticks + q, tk[q + 1] - tk[q]);
+                atomicAdd(phase_ticks + 4, 1ull);
+            }
         }
     }
 }
@@ -1036,6 +1147,8 @@ struct cymf_wmf {
     int32_t seg_len = 0;            // 0: default (see set_data); CYMF_WMF_SEG
     DevBuf<cymf::WmfSeg> d_segs[2];
     DevBuf<int32_t> d_long_rows[2];
+    DevBuf<float> d_a0t;            // (YtY + lambda I) / (w - 1) in the accumulator tile layout (wmf_tile_layout_kernel)
+    DevBuf<unsigned long long> d_ticks;   // CYMF_WMF_PROBE=5: [side][8] phase ticks of wmf_row_blk_kernel
     DevBuf<int32_t> d_order[2];     // this rank's whole rows (offsets from its first row), longest first: the row kernels' work list
     int32_t n_order[2] = {0, 0};
     int32_t n_segs[2] = {0, 0}, n_long[2] = {0, 0};
@@ -1145,8 +1258,12 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
         if (my_rows <= 0) {                                                                                                 \
         } else if (h->reg_solve && h->weight != 1.0 && (h->blocked >= 0 ? h->blocked != 0 : (T32_) >= 3)) {                 \
             const int grid_b = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
-            hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), 0, h->stream, n_work, ip, ix, Xf, Yf, Gf, \
-                               (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order);                       \
+            constexpr int n_a0t = (T32_) * ((T32_) + 1) / 2 * 1024;                                                         \
+            CYMF_TRY(h->d_a0t.alloc(n_a0t));                                                                                \
+            hipLaunchKernelGGL((wmf_tile_layout_kernel<T32_>), dim3(n_a0t / 256), dim3(256), 0, h->stream, Gf,               \
+                               (float)(1.0 / (h->weight - 1.0)), h->d_a0t.p);                                               \
+            hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), 0, h->stream, n_work, ip, ix, Xf, Yf, h->d_a0t.p, \
+                               (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_ticks.p);         \
         } else if (h->reg_solve && h->weight != 1.0) {                                                                      \
             constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                        \
             const size_t smem_r = wmf_reg_smem<T32_, NW_>();                                                                \
@@ -1208,6 +1325,15 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             hipLaunchKernelGGL(wmf_row_kernel<T>, dim3(grid_g), dim3(WMF_THREADS), smem, h->stream, my_rows, K, ip, ix, X, Y, st.G.p, (T)h->weight, scratch);
     }
     CYMF_HIP(hipGetLastError());
+    if (h->probe == 5) {   // phase ticks of wmf_row_blk_kernel (diagnostic: synchronises)
+        unsigned long long t[8] = {0};
+        CYMF_HIP(hipMemcpyAsync(t, h->d_ticks.p, sizeof(t), hipMemcpyDeviceToHost, h->stream));
+        CYMF_HIP(hipStreamSynchronize(h->stream));
+        if (t[4])
+            fprintf(stderr, "[wmf probe 5] side %d: %llu rows; s_memtime ticks per row: A0 %.0f, Gramian %.0f, factorisation %.0f, back substitution %.0f\n",
+                    side, t[4], (double)t[0] / t[4], (double)t[1] / t[4], (double)t[2] / t[4], (double)t[3] / t[4]);
+        CYMF_TRY(h->d_ticks.zero(h->stream));
+    }
     if (h->comm && !h->bounds[side].empty())   // every rank ends the half-sweep with the whole updated table
         CYMF_TRY(comm_allgatherv(h->comm, X_all, h->bounds[side].data(), (int64_t)K * (int64_t)sizeof(T), h->stream));
     return 0;
@@ -1333,6 +1459,8 @@ extern "C" int cymf_wmf_set_data(cymf_wmf *h, const int32_t *indptr, const int32
         max_long = std::max(max_long, longs.size());
     }
     CYMF_TRY(h->d_scratch.alloc(std::max<size_t>(1, max_long * ((size_t)h->K * h->K + h->K))));
+    CYMF_TRY(h->d_ticks.alloc(8));
+    CYMF_TRY(h->d_ticks.zero(h->stream));
     {
         std::vector<int32_t> iota((size_t)std::max(h->U, h->I));
         for (size_t v = 0; v < iota.size(); ++v) iota[v] = (int32_t)v;
