@@ -739,93 +739,6 @@ __device__ __forceinline__ float lane_value(float v, int l) {   // v_readlane_b3
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-// Step C of the Cholesky factorisation of block row P (upper factor, A = U^T U) in the C layout.  Row C of a tile lies in
-// register RC of the lanes of half LC, element j in lane j -- which is exactly the operand layout of v_mfma_f32_32x32x2_f32
-// (lane l supplies A[l & 31][l >> 5] and B[l >> 5][l & 31]); with the other half's operands zero, one MFMA per tile is the
-// rank-1 update of the step:  row C <- row C / sqrt(d)  (= row C of U and of S(P,n) = U^-T T(P,n)),  rows i > C of every tile
-// of the block row -= U[C][i] * (row C).  U[C][i] is taken from row C of the diagonal tile: the tile is symmetric up to
-// rounding.  Rows <= C are not touched (A operand masked); what the updates write below the diagonal of the diagonal tile is
-// never read.  The right-hand side rides along (forward substitution, lane layout): only the copy in half LC is current, the
-// halves are synchronised every fourth step (rows C..C+3 share a half).
-template <int T32, int P, int C>
-__device__ __forceinline__ void chol_step(f32x16 (&acc)[T32 * (T32 + 1) / 2], float &bcur, float &ycur, float &rsd, int li, int lh) {
-    constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;
-    f32x16 &D = acc[blk_tix(P, P)];
-    const bool mine = lh == LC;
-    const float prow = D[RC];
-    const float rs = rsq_nr(lane_value(prow, C + 32 * LC));
-    const float urow = prow * rs;
-    D[RC] = mine ? urow : prow;
-    const float aop = mine && li > C ? -urow : 0.0f;
-    D = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, mine ? urow : 0.0f, D, 0, 0, 0);
-#pragma unroll
-    for (int n = P + 1; n < T32; ++n) {
-        f32x16 &S = acc[blk_tix(P, n)];
-        const float srow = S[RC] * rs;
-        S[RC] = mine ? srow : S[RC];
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, mine ? srow : 0.0f, S, 0, 0, 0);
-    }
-    const float yc = lane_value(bcur, C + 32 * LC) * rs;
-    ycur = li == C ? yc : ycur;
-    rsd = li == C ? rs : rsd;
-    // pinned: left alone, the compiler keeps the 32 (yc, rs) pairs of a block row alive and builds the two vectors where they
-    // are first read -- 64 registers per block row, paid for with accumulator tiles in scratch
-    asm volatile("" : "+v"(ycur), "+v"(rsd));
-    bcur = __builtin_fmaf(aop, yc, bcur);
-    if constexpr ((C & 3) == 3 && C + 1 < 32) bcur = half_bcast(bcur, LC);
-    if constexpr (C + 1 < 32) chol_step<T32, P, C + 1>(acc, bcur, ycur, rsd, li, lh);
-}
-
-// Step C (descending) of x = U^-1 w with the transposed tile L = U^T in the C layout: row C of L is column C of U, in lane layout.
-template <int C>
-__device__ __forceinline__ void back_step(const f32x16 &L, float &w, float &x, float rsd, int li, int lh) {
-    constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;
-    const bool mine = lh == LC;
-    const float xc = lane_value(w, C + 32 * LC) * lane_value(rsd, C);
-    x = li == C ? xc : x;
-    asm volatile("" : "+v"(x));
-    w = __builtin_fmaf(mine && li < C ? -L[RC] : 0.0f, xc, w);
-    if constexpr ((C & 3) == 0 && C > 0) w = half_bcast(w, LC);
-    if constexpr (C > 0) back_step<C - 1>(L, w, x, rsd, li, lh);
-}
-
-template <int T32, int P>
-__device__ __forceinline__ void chol_panels(f32x16 (&acc)[T32 * (T32 + 1) / 2], float (&bl)[T32], float (&y)[T32], float (&rsd)[T32], int li, int lh) {
-    y[P] = 0.0f;
-    rsd[P] = 0.0f;
-    __builtin_amdgcn_sched_barrier(0);
-    chol_step<T32, P, 0>(acc, bl[P], y[P], rsd[P], li, lh);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (P + 1 < T32) {
-        // T(m,n) -= S(P,m)^T S(P,n), P < m <= n: registers r of S(P,m) and of S(P,n) are the operands as they lie.  The tiles
-        // of the later block rows are kept NEGATED until their own block row is factored (the kernel negates them once after
-        // the Gramian, the block row is negated back below): the update is then an addition and needs no negated copy of
-        // S(P,m) -- a 16-register temporary per m that, with the register file fragmented by 160 accumulator registers,
-        // made the compiler spill whole tiles.
-#pragma unroll
-        for (int m = P + 1; m < T32; ++m)
-#pragma unroll
-            for (int n = m; n < T32; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[blk_tix(m, n)] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[blk_tix(P, m)][r], acc[blk_tix(P, n)][r], acc[blk_tix(m, n)], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        float yreg[16];                                         // y_P[k(r, lh)]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yreg[r] = __shfl(y[P], (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
-#pragma unroll
-        for (int m = P + 1; m < T32; ++m) {
-            float part = 0.0f;                                  // b_m -= S(P,m)^T y_P
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part = __builtin_fmaf(acc[blk_tix(P, m)][r], yreg[r], part);
-            bl[m] -= part + other_half(part, lh);
-        }
-#pragma unroll
-        for (int n = P + 1; n < T32; ++n) acc[blk_tix(P + 1, n)] = -acc[blk_tix(P + 1, n)];   // block row P + 1 comes next
-        chol_panels<T32, P + 1>(acc, bl, y, rsd, li, lh);
-    }
-}
-
 // sum over the 32 lanes of each half-wave, returned in every lane of the half
 __device__ __forceinline__ float half_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -835,6 +748,95 @@ __device__ __forceinline__ float half_sum(float v) {
     float even, odd;   // {rows 0 0 2 2, rows 1 1 3 3}
     asm("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\tv_permlane16_swap_b32 %0, %1" : "=&v"(even), "=&v"(odd) : "v"(v));
     return even + odd;
+}
+
+// Step C of the Cholesky factorisation T(P,P) = U^T U of a diagonal tile in the C layout, with the same row operations applied
+// to a tile E that starts as the identity (afterwards E = U^-T, lower triangular).  Row C of a tile lies in register RC of
+// the lanes of half LC, element j in lane j -- which is exactly the operand layout of v_mfma_f32_32x32x2_f32 (lane l supplies
+// A[l & 31][l >> 5] and B[l >> 5][l & 31]); with the other half's operands zero, one MFMA per tile is the rank-1 update of the
+// step:  row C <- row C / sqrt(d),  rows i > C -= U[C][i] * (row C).  U[C][i] is taken from row C of the tile itself: the
+// trailing part is symmetric up to rounding.  Rows <= C are not touched (A operand masked); what the updates write below the
+// diagonal of the tile is never read.
+template <int C>
+__device__ __forceinline__ void chol_step(f32x16 &D, f32x16 &E, int li, int lh) {
+    constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;
+    const bool mine = lh == LC;
+    const float prow = D[RC];
+    const float rs = rsq_nr(lane_value(prow, C + 32 * LC));
+    const float urow = prow * rs;
+    D[RC] = mine ? urow : prow;
+    const float aop = mine && li > C ? -urow : 0.0f;
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, mine ? urow : 0.0f, D, 0, 0, 0);
+    const float erow = E[RC] * rs;
+    E[RC] = mine ? erow : E[RC];
+    E = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, mine ? erow : 0.0f, E, 0, 0, 0);
+    if constexpr (C + 1 < 32) chol_step<C + 1>(D, E, li, lh);
+}
+
+// value of lane-layout vector v (element j in lanes j and j + 32) at this lane's row of register r
+__device__ __forceinline__ float to_reg_layout(float v, int r, int lh) { return __shfl(v, (r & 3) + 8 * (r >> 2) + 4 * lh, 64); }
+
+template <int T32, int P>
+__device__ __forceinline__ void chol_panels(f32x16 (&acc)[T32 * (T32 + 1) / 2], float (&bl)[T32], float (&y)[T32], int li, int lh) {
+    f32x16 &D = acc[blk_tix(P, P)];
+    {
+        f32x16 E;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) E[r] = li == (r & 3) + 8 * (r >> 2) + 4 * lh ? 1.0f : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+        chol_step<0>(D, E, li, lh);
+        __builtin_amdgcn_sched_barrier(0);
+        D = E;                                                  // U is dead; U^-T stays for the back substitution
+    }
+    if constexpr (P + 1 < T32) {
+        // V = U^-1 = E^T through the matrix unit (D[i][j] = sum_k E[k][i] I[k][j]): register r of V is the A operand of E * T
+        f32x16 V = (f32x16)(0.0f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            V = __builtin_amdgcn_mfma_f32_32x32x2f32(D[r], li == (r & 3) + 8 * (r >> 2) + 4 * lh ? 1.0f : 0.0f, V, 0, 0, 0);
+        float part = 0.0f;                                      // y_P = U^-T b_P = E b_P: column sums of V against b in register layout
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part = __builtin_fmaf(V[r], to_reg_layout(bl[P], r, lh), part);
+        y[P] = part + other_half(part, lh);
+#pragma unroll
+        for (int n = P + 1; n < T32; ++n) {                     // S(P,n) = U^-T T(P,n) = E T(P,n); b_n -= S(P,n)^T y_P
+            f32x16 R = (f32x16)(0.0f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) R = __builtin_amdgcn_mfma_f32_32x32x2f32(V[r], acc[blk_tix(P, n)][r], R, 0, 0, 0);
+            float yp = y[P];
+            asm volatile("" : "+v"(yp));                        // y_P in register layout is re-fetched per tile: held across the tiles it costs 16 registers
+            float pn = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pn = __builtin_fmaf(R[r], to_reg_layout(yp, r, lh), pn);
+            bl[n] -= pn + other_half(pn, lh);
+            acc[blk_tix(P, n)] = R;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // T(m,n) -= S(P,m)^T S(P,n), P < m <= n: registers r of S(P,m) and of S(P,n) are the operands as they lie.  The tiles
+        // of the later block rows are kept NEGATED until their own block row is factored (the kernel negates them once after
+        // the Gramian, the block row is negated back below): the update is then an addition and needs no negated copy of S(P,m).
+#pragma unroll
+        for (int m = P + 1; m < T32; ++m)
+#pragma unroll
+            for (int n = m; n < T32; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[blk_tix(m, n)] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[blk_tix(P, m)][r], acc[blk_tix(P, n)][r], acc[blk_tix(m, n)], 0, 0, 0);
+#pragma unroll
+        for (int n = P + 1; n < T32; ++n) acc[blk_tix(P + 1, n)] = -acc[blk_tix(P + 1, n)];   // block row P + 1 comes next
+        chol_panels<T32, P + 1>(acc, bl, y, li, lh);
+    } else {
+        // last block row: y_P = E b_P directly, row sums of E against b in lane layout
+        float sel = 0.0f;
+        const int rj = (li & 3) + 4 * (li >> 3), lj = (li >> 2) & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sr = half_sum(D[r] * bl[P]);
+            sel = r == rj ? sr : sel;
+        }
+        const float other = other_half(sel, lh);
+        y[P] = lh == lj ? sel : other;
+    }
 }
 
 template <int T32>
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
         li = lane & 31;
         lh = lane >> 5;
         if (probe == 5) { asm volatile("" : "+v"(acc[0][0])); tk[2] = __builtin_amdgcn_s_memtime(); }
-        float bl[T32], y[T32], rsd[T32];                        // b_m, y_m = (U^-T b)_m, 1 / diag(U)_m: element j in lanes j and j + 32
+        float bl[T32], y[T32];                                  // b_m, y_m = (U^-T b)_m: element j in lanes j and j + 32
 #pragma unroll
         for (int m = 0; m < T32; ++m) bl[m] = (bsum[m] + other_half(bsum[m], lh)) * (weight * inv_w1);
         if (probe == 1) {                                       // timing probe: no elimination
@@ -940,9 +942,10 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (tile_m(t) >= 1) acc[t] = -acc[t];              // (see chol_panels: later block rows are carried negated)
-        chol_panels<T32, 0>(acc, bl, y, rsd, li, lh);
+        chol_panels<T32, 0>(acc, bl, y, li, lh);
         if (probe == 5) { asm volatile("" : "+v"(y[T32 - 1])); tk[3] = __builtin_amdgcn_s_memtime(); }
-        // back substitution: x_p = U_pp^-1 (y_p - sum_{n > p} S(p,n) x_n)
+        // back substitution: x_p = U_pp^-1 (y_p - sum_{n > p} S(p,n) x_n) = E_p^T (...): the sums over n are row sums of the S tiles
+        // against x in lane layout, the product with E^T a column sum against the result in register layout
         float x[T32];
         const int rj = (li & 3) + 4 * (li >> 3), lj = (li >> 2) & 1;   // where row li of a tile lives
 #pragma unroll
@@ -962,13 +965,10 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
                 const float other = other_half(sel, lh);
                 w -= lh == lj ? sel : other;
             }
-            // L = U_pp^T through the matrix unit (D[i][j] = sum_k U[k][i] I[k][j]): its rows are the columns of U in lane layout
-            f32x16 L = (f32x16)(0.0f);
+            float part = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                L = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[blk_tix(p, p)][r], li == (r & 3) + 8 * (r >> 2) + 4 * lh ? 1.0f : 0.0f, L, 0, 0, 0);
-            x[p] = 0.0f;
-            back_step<31>(L, w, x[p], rsd[p], li, lh);
+            for (int r = 0; r < 16; ++r) part = __builtin_fmaf(acc[blk_tix(p, p)][r], to_reg_layout(w, r, lh), part);
+            x[p] = part + other_half(part, lh);
         }
         if (lh == 0) {
 #pragma unroll
@@ -1009,28 +1009,36 @@ __global__ __launch_bounds__(WMF_THREADS, 2) void wmf_seg_kernel(const int32_t *
         for (int t = 0; t < NT; ++t) acc[t] = (f32x16)(0.0f);
 #pragma unroll
         for (int m = 0; m < T32; ++m) bsum[m] = 0.0f;
+        const char *Yb = reinterpret_cast<const char *>(Y);
         for (int32_t pb = p0; pb < p1; pb += 64) {
             const int32_t myp = pb + lane;
             const int32_t myidx = myp < p1 ? indices[myp] : -1;
             const int nb = p1 - pb < 64 ? p1 - pb : 64;
             const int steps = (nb + 1) >> 1;                     // <= 32: one pass of 8 steps per wave
-            for (int s0 = wave; s0 < steps; s0 += 32) {          // (runs once; written as the loop of wmf_row_reg_kernel)
+            if (wave < steps) {
+                // one 32-bit byte offset per gathered row, chunk offsets as immediates, unconditional loads selected afterwards
+                // (as in wmf_row_blk_kernel; the host sends tables beyond 4 GB to the tile-dealing kernel)
                 float ch[8][T32];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int32_t idx = __shfl(myidx, 2 * (s0 + 4 * u) + lh, 64);
-                    const bool ok = idx >= 0 && s0 + 4 * u < steps;
-                    const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
+                    const int32_t idx = __shfl(myidx, 2 * (wave + 4 * u) + lh, 64);
+                    const bool ok = idx >= 0 && wave + 4 * u < steps;
+                    const uint32_t off = (uint32_t)(ok ? idx : 0) * (uint32_t)(K * 4) + (uint32_t)(li * 4);
 #pragma unroll
-                    for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
+                    for (int m = 0; m < T32; ++m) {
+                        const float v = *reinterpret_cast<const float *>(Yb + off + 128 * m);
+                        ch[u][m] = ok ? v : 0.0f;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
+                    if (wave + 4 * u < steps) {                  // (uniform)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
 #pragma unroll
-                    for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
+                        for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
+                    }
                 }
             }
         }
@@ -1190,6 +1198,8 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
     CYMF_TRY(st.G.alloc((size_t)K * K + K));   // K*K Gramian (+ K: the column sums the MFMA path also produces)
     CYMF_TRY(st.G.zero(h->stream));
     const bool mfma_ok = sizeof(T) == 4 && h->use_mfma && K % 32 == 0 && K <= 128;
+    // the one-wave kernels address the gathered table with 32-bit byte offsets: tables of 4 GB and more take the older kernels
+    const bool reg_ok = h->reg_solve && (int64_t)cols * K * 4 < ((int64_t)1 << 32);
     if (mfma_ok) {
         // YtY on the MFMA units: Y as ONE long "row" over the identity index list, cut into segments, each
         // workgroup adding its partial 32x32 tiles into G (the segment instantiation of the row kernel)
@@ -1199,7 +1209,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             const int ns = h->n_gram_segs[g];
 #define WMF_GRAM_(T32_)                                                                                                       \
     do {                                                                                                                      \
-        if (h->reg_solve) {                                                                                                   \
+        if (reg_ok) {                                                                                                         \
             hipLaunchKernelGGL((wmf_seg_kernel<T32_>), dim3(ns), dim3(WMF_THREADS), 0, h->stream, h->d_iota.p,                \
                                reinterpret_cast<const float *>(Y), h->d_gram_segs[g].p, ns, reinterpret_cast<float *>(st.G.p)); \
         } else {                                                                                                              \
@@ -1249,14 +1259,14 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
     do {                                                                                                                    \
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, false>, smem));                                                        \
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, true>, smem));                                                         \
-        if (nseg > 0 && h->reg_solve)   /* segments of the long rows first: the longest work starts earliest */             \
+        if (nseg > 0 && reg_ok)   /* segments of the long rows first: the longest work starts earliest */                   \
             hipLaunchKernelGGL((wmf_seg_kernel<T32_>), dim3(grid_seg), dim3(WMF_THREADS), 0, h->stream, ix, Yf, segs, nseg,  \
                                h->d_scratch.p);                                                                             \
         else if (nseg > 0)                                                                                                  \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, my_rows, \
                                ip, ix, Xf, Yf, Gf, (float)h->weight, h->long_threshold, segs, nseg, h->d_scratch.p);        \
         if (my_rows <= 0) {                                                                                                 \
-        } else if (h->reg_solve && h->weight != 1.0 && (h->blocked >= 0 ? h->blocked != 0 : (T32_) >= 3)) {                 \
+        } else if (reg_ok && h->weight != 1.0 && (h->blocked >= 0 ? h->blocked != 0 : (T32_) >= 3)) {                      \
             const int grid_b = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
             constexpr int n_a0t = (T32_) * ((T32_) + 1) / 2 * 1024;                                                         \
             CYMF_TRY(h->d_a0t.alloc(n_a0t));                                                                                \
@@ -1264,7 +1274,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
                                (float)(1.0 / (h->weight - 1.0)), h->d_a0t.p);                                               \
             hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), 0, h->stream, n_work, ip, ix, Xf, Yf, h->d_a0t.p, \
                                (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_ticks.p);         \
-        } else if (h->reg_solve && h->weight != 1.0) {                                                                      \
+        } else if (reg_ok && h->weight != 1.0) {                                                                           \
             constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                        \
             const size_t smem_r = wmf_reg_smem<T32_, NW_>();                                                                \
             const int grid_r = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
@@ -1289,7 +1299,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             default: WMF_LAUNCH_(4); break;
             }
 #undef WMF_LAUNCH_
-            if (nlong > 0 && h->reg_solve) {
+            if (nlong > 0 && reg_ok) {
 #define WMF_FINISH_(T32_)                                                                                                   \
     do {                                                                                                                    \
         constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                            \
