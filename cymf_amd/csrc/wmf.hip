@@ -839,6 +839,196 @@ __device__ __forceinline__ void chol_panels(f32x16 (&acc)[T32 * (T32 + 1) / 2], 
     }
 }
 
+// ---- K = 128: the same elimination with idle tiles parked in LDS -------------------------------------------------------
+// Ten accumulator tiles are 160 of the 256 registers two waves per SIMD leave a lane; with the working tiles of a block row
+// (E, V, R) on top the compiler kept whole tiles in scratch and fetched them back around every phase (1 KB per lane, and a
+// scratch round trip is a memory latency inside what is already a latency chain).  The schedule below says explicitly which
+// four tiles are NOT needed next and keeps them in the workgroup's 16 KB of LDS (one wave per workgroup, eight per CU: 128 of
+// 160 KB): at most six tiles plus the three working tiles are in registers at any time.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void park_put(f32x4 *park, int slot, int lane, const f32x16 &t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) park[(slot * 4 + q) * 64 + lane] = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+}
+__device__ __forceinline__ void park_get(const f32x4 *park, int slot, int lane, f32x16 &t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = park[(slot * 4 + q) * 64 + lane];
+        t[4 * q] = v[0]; t[4 * q + 1] = v[1]; t[4 * q + 2] = v[2]; t[4 * q + 3] = v[3];
+    }
+}
+// D <- U^-T of the diagonal tile D (chol_step), V <- U^-1, returns y = U^-T b (lane layout)
+__device__ __forceinline__ float blk_factor(f32x16 &D, f32x16 &V, float b, int li, int lh) {
+    {
+        f32x16 E;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) E[r] = li == (r & 3) + 8 * (r >> 2) + 4 * lh ? 1.0f : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+        chol_step<0>(D, E, li, lh);
+        __builtin_amdgcn_sched_barrier(0);
+        D = E;
+    }
+    V = (f32x16)(0.0f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        V = __builtin_amdgcn_mfma_f32_32x32x2f32(D[r], li == (r & 3) + 8 * (r >> 2) + 4 * lh ? 1.0f : 0.0f, V, 0, 0, 0);
+    float part = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part = __builtin_fmaf(V[r], to_reg_layout(b, r, lh), part);
+    return part + other_half(part, lh);
+}
+// T <- S = U^-T T (A operand: registers of V), bn -= S^T y
+__device__ __forceinline__ void blk_panel_tile(const f32x16 &V, f32x16 &T, float y, float &bn, int lh) {
+    f32x16 R = (f32x16)(0.0f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R = __builtin_amdgcn_mfma_f32_32x32x2f32(V[r], T[r], R, 0, 0, 0);
+    asm volatile("" : "+v"(y));
+    float pn = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pn = __builtin_fmaf(R[r], to_reg_layout(y, r, lh), pn);
+    bn -= pn + other_half(pn, lh);
+    T = R;
+}
+// C += A^T B (C is carried negated: see chol_panels)
+__device__ __forceinline__ void blk_trail(const f32x16 &A, const f32x16 &B, f32x16 &C) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r], B[r], C, 0, 0, 0);
+}
+__device__ __forceinline__ void blk_trail_parked(const f32x16 &A, const f32x16 &B, f32x4 *park, int slot, int lane) {
+    f32x16 C;
+    park_get(park, slot, lane, C);
+    blk_trail(A, B, C);
+    park_put(park, slot, lane, C);
+}
+// s[r] += S[r] * x (row sums of S against x are finished by blk_rows_to_lanes)
+__device__ __forceinline__ void blk_row_acc(const f32x16 &S, float x, float (&s)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = __builtin_fmaf(S[r], x, s[r]);
+}
+__device__ __forceinline__ float blk_rows_to_lanes(float (&s)[16], int li, int lh) {   // sum over the lanes of each register's row -> lane layout
+    const int rj = (li & 3) + 4 * (li >> 3), lj = (li >> 2) & 1;
+    float sel = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float sr = half_sum(s[r]);
+        sel = r == rj ? sr : sel;
+    }
+    const float other = other_half(sel, lh);
+    return lh == lj ? sel : other;
+}
+__device__ __forceinline__ float blk_apply_Et(const f32x16 &E, float w, int lh) {      // U^-1 w = E^T w: column sums of E against w in register layout
+    float part = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part = __builtin_fmaf(E[r], to_reg_layout(w, r, lh), part);
+    return part + other_half(part, lh);
+}
+
+// acc: the ten tiles of a K=128 system (later block rows negated), bl: b in lane layout; x <- the solution (lane layout per block)
+__device__ __forceinline__ void blk_solve_parked4(f32x16 (&acc)[10], float (&bl)[4], float (&x)[4], f32x4 *park, int lane, int li, int lh) {
+    f32x16 &t00 = acc[blk_tix(0, 0)], &t01 = acc[blk_tix(0, 1)], &t02 = acc[blk_tix(0, 2)], &t03 = acc[blk_tix(0, 3)];
+    f32x16 &t11 = acc[blk_tix(1, 1)], &t12 = acc[blk_tix(1, 2)], &t13 = acc[blk_tix(1, 3)];
+    f32x16 &t22 = acc[blk_tix(2, 2)], &t23 = acc[blk_tix(2, 3)], &t33 = acc[blk_tix(3, 3)];
+    float y[4];
+    park_put(park, 0, lane, t13);
+    park_put(park, 1, lane, t22);
+    park_put(park, 2, lane, t23);
+    park_put(park, 3, lane, t33);
+    {   // block row 0
+        f32x16 V;
+        y[0] = blk_factor(t00, V, bl[0], li, lh);
+        blk_panel_tile(V, t01, y[0], bl[1], lh);
+        blk_panel_tile(V, t02, y[0], bl[2], lh);
+        blk_panel_tile(V, t03, y[0], bl[3], lh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    blk_trail(t01, t01, t11);
+    blk_trail(t01, t02, t12);
+    blk_trail_parked(t01, t03, park, 0, lane);
+    blk_trail_parked(t02, t02, park, 1, lane);
+    blk_trail_parked(t02, t03, park, 2, lane);
+    blk_trail_parked(t03, t03, park, 3, lane);
+    park_get(park, 0, lane, t13);
+    park_put(park, 0, lane, t00);                              // E_0 rests until the back substitution
+    t11 = -t11; t12 = -t12; t13 = -t13;
+    __builtin_amdgcn_sched_barrier(0);
+    {   // block row 1
+        f32x16 V;
+        y[1] = blk_factor(t11, V, bl[1], li, lh);
+        blk_panel_tile(V, t12, y[1], bl[2], lh);
+        blk_panel_tile(V, t13, y[1], bl[3], lh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    blk_trail_parked(t12, t12, park, 1, lane);
+    blk_trail_parked(t12, t13, park, 2, lane);
+    blk_trail_parked(t13, t13, park, 3, lane);
+    park_get(park, 1, lane, t22);
+    park_get(park, 2, lane, t23);
+    park_put(park, 1, lane, t01);
+    park_put(park, 2, lane, t02);
+    t22 = -t22; t23 = -t23;
+    __builtin_amdgcn_sched_barrier(0);
+    {   // block row 2
+        f32x16 V;
+        y[2] = blk_factor(t22, V, bl[2], li, lh);
+        blk_panel_tile(V, t23, y[2], bl[3], lh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    blk_trail_parked(t23, t23, park, 3, lane);
+    park_get(park, 3, lane, t33);
+    park_put(park, 3, lane, t03);
+    t33 = -t33;
+    __builtin_amdgcn_sched_barrier(0);
+    {   // block row 3: y_3 = E b_3 directly (row sums of E against b in lane layout)
+        f32x16 E;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) E[r] = li == (r & 3) + 8 * (r >> 2) + 4 * lh ? 1.0f : 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+        chol_step<0>(t33, E, li, lh);
+        __builtin_amdgcn_sched_barrier(0);
+        t33 = E;
+        float s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+        blk_row_acc(t33, bl[3], s);
+        y[3] = blk_rows_to_lanes(s, li, lh);
+    }
+    // back substitution
+    x[3] = blk_apply_Et(t33, y[3], lh);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+        blk_row_acc(t23, x[3], s);
+        x[2] = blk_apply_Et(t22, y[2] - blk_rows_to_lanes(s, li, lh), lh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+        blk_row_acc(t12, x[2], s);
+        blk_row_acc(t13, x[3], s);
+        x[1] = blk_apply_Et(t11, y[1] - blk_rows_to_lanes(s, li, lh), lh);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+        f32x16 T;
+        park_get(park, 1, lane, T);
+        blk_row_acc(T, x[1], s);
+        park_get(park, 2, lane, T);
+        blk_row_acc(T, x[2], s);
+        park_get(park, 3, lane, T);
+        blk_row_acc(T, x[3], s);
+        const float w = y[0] - blk_rows_to_lanes(s, li, lh);
+        park_get(park, 0, lane, T);
+        x[0] = blk_apply_Et(T, w, lh);
+    }
+}
+
 template <int T32>
 __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const int32_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices, float *__restrict__ X,
@@ -942,33 +1132,39 @@ __global__ __launch_bounds__(64, 2) void wmf_row_blk_kernel(int32_t rows, const 
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (tile_m(t) >= 1) acc[t] = -acc[t];              // (see chol_panels: later block rows are carried negated)
-        chol_panels<T32, 0>(acc, bl, y, li, lh);
-        if (probe == 5) { asm volatile("" : "+v"(y[T32 - 1])); tk[3] = __builtin_amdgcn_s_memtime(); }
-        // back substitution: x_p = U_pp^-1 (y_p - sum_{n > p} S(p,n) x_n) = E_p^T (...): the sums over n are row sums of the S tiles
-        // against x in lane layout, the product with E^T a column sum against the result in register layout
         float x[T32];
-        const int rj = (li & 3) + 4 * (li >> 3), lj = (li >> 2) & 1;   // where row li of a tile lives
+        if constexpr (T32 == 4) {
+            extern __shared__ f32x4 park_lds[];                 // [4 tiles][4][64 lanes]
+            blk_solve_parked4(acc, bl, x, park_lds, lane, li, lh);
+            if (probe == 5) { asm volatile("" : "+v"(x[0])); tk[3] = __builtin_amdgcn_s_memtime(); }
+        } else {
+            chol_panels<T32, 0>(acc, bl, y, li, lh);
+            if (probe == 5) { asm volatile("" : "+v"(y[T32 - 1])); tk[3] = __builtin_amdgcn_s_memtime(); }
+            // back substitution: x_p = U_pp^-1 (y_p - sum_{n > p} S(p,n) x_n) = E_p^T (...): the sums over n are row sums of the S tiles
+            // against x in lane layout, the product with E^T a column sum against the result in register layout
+            const int rj = (li & 3) + 4 * (li >> 3), lj = (li >> 2) & 1;   // where row li of a tile lives
 #pragma unroll
-        for (int p = T32 - 1; p >= 0; --p) {
-            __builtin_amdgcn_sched_barrier(0);
-            float w = y[p];
-            if (p + 1 < T32) {
-                float sel = 0.0f;
+            for (int p = T32 - 1; p >= 0; --p) {
+                __builtin_amdgcn_sched_barrier(0);
+                float w = y[p];
+                if (p + 1 < T32) {
+                    float sel = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float sr = 0.0f;
+                    for (int r = 0; r < 16; ++r) {
+                        float sr = 0.0f;
 #pragma unroll
-                    for (int n = p + 1; n < T32; ++n) sr = __builtin_fmaf(acc[blk_tix(p, n)][r], x[n], sr);
-                    sr = half_sum(sr);                          // (S(p,.) x)[k(r, lh)], in every lane of the half
-                    sel = r == rj ? sr : sel;
+                        for (int n = p + 1; n < T32; ++n) sr = __builtin_fmaf(acc[blk_tix(p, n)][r], x[n], sr);
+                        sr = half_sum(sr);                          // (S(p,.) x)[k(r, lh)], in every lane of the half
+                        sel = r == rj ? sr : sel;
+                    }
+                    const float other = other_half(sel, lh);
+                    w -= lh == lj ? sel : other;
                 }
-                const float other = other_half(sel, lh);
-                w -= lh == lj ? sel : other;
-            }
-            float part = 0.0f;
+                float part = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part = __builtin_fmaf(acc[blk_tix(p, p)][r], to_reg_layout(w, r, lh), part);
-            x[p] = part + other_half(part, lh);
+                for (int r = 0; r < 16; ++r) part = __builtin_fmaf(acc[blk_tix(p, p)][r], to_reg_layout(w, r, lh), part);
+                x[p] = part + other_half(part, lh);
+            }
         }
         if (lh == 0) {
 #pragma unroll
@@ -1272,7 +1468,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             CYMF_TRY(h->d_a0t.alloc(n_a0t));                                                                                \
             hipLaunchKernelGGL((wmf_tile_layout_kernel<T32_>), dim3(n_a0t / 256), dim3(256), 0, h->stream, Gf,               \
                                (float)(1.0 / (h->weight - 1.0)), h->d_a0t.p);                                               \
-            hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), 0, h->stream, n_work, ip, ix, Xf, Yf, h->d_a0t.p, \
+            hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), (T32_) == 4 ? 16384 : 0, h->stream, n_work, ip, ix, Xf, Yf, h->d_a0t.p, \
                                (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_ticks.p);         \
         } else if (reg_ok && h->weight != 1.0) {                                                                           \
             constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                        \
@@ -1462,6 +1658,8 @@ extern "C" int cymf_wmf_set_data(cymf_wmf *h, const int32_t *indptr, const int32
         });
         h->n_order[side] = (int32_t)order.size();
         CYMF_TRY(h->d_order[side].upload(order.data(), order.size(), h->stream));
+        // (segments stay in row order: sorted longest first, the segments of one very long row run together and contend for
+        // the atomics on its scratch slot -- measured 3.3 instead of 2.9 ms for the C4 item sweep at K=128)
         h->n_segs[side] = (int32_t)segs.size();
         h->n_long[side] = (int32_t)longs.size();
         CYMF_TRY(h->d_segs[side].upload(segs.data(), segs.size(), h->stream));

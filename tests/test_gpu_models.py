@@ -295,6 +295,43 @@ def test_wmf_register_and_lds_solvers_agree(K, monkeypatch):
     assert (out[0][0][3] == 0).all()
 
 
+@pytest.mark.parametrize("K", [96, 128])
+def test_wmf_blocked_cholesky_rows_of_every_kind(K, monkeypatch):
+    """K = 96 / 128 run the one-wave blocked Cholesky (wmf_row_blk_kernel; at 128 with tiles parked in LDS): rows of 0, 1, 2, 63, 64, 65
+    and 200 entries (odd / even k=2 steps, batch boundaries), rows beyond the segment threshold (CYMF_WMF_LONG=64: built from
+    segments, finished by the register solve), against the f64 oracle; and the longest-first work list is only an ORDER -- the
+    sweep in index order (CYMF_WMF_ROW_ORDER=0) returns the same solution (up to the f32 noise of two launches: YtY and the
+    long rows are summed with float atomics, whose order differs from launch to launch, and the solve amplifies that by the
+    condition number)."""
+    rs = np.random.RandomState(5)
+    U, I = 400, 500                                                       # both tables have more rows than K: YtY is not rank-deficient
+    lens = [0, 1, 2, 63, 64, 65, 200] + list(rs.randint(1, 60, size=U - 7))
+    rows = np.concatenate([np.full(n, u) for u, n in enumerate(lens)]).astype(np.int64)
+    cols = np.concatenate([rs.choice(I, size=n, replace=False) for n in lens]).astype(np.int64)
+    from scipy import sparse
+    X = sparse.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, I))
+    Xt = X.T.tocsr()
+    W0, H0 = oracle.reference_init(U, I, K)
+    W, H = W0.copy(), H0.copy()
+    oracle.wmf_half_sweep(X.indptr, X.indices, W, H, 10.0, 0.01)
+    oracle.wmf_half_sweep(Xt.indptr, Xt.indices, H, W, 10.0, 0.01)
+    monkeypatch.setenv("CYMF_WMF_LONG", "64")
+    out = []
+    for order in ("1", "0"):
+        monkeypatch.setenv("CYMF_WMF_ROW_ORDER", order)
+        t = WmfTrainer(U, I, K, 10.0, 0.01, dtype="float32")
+        t.set_data(X.indptr, X.indices, Xt.indptr, Xt.indices)
+        t.upload(W0, H0)
+        t.epochs(1)
+        gW, gH = np.empty_like(W0), np.empty_like(H0)
+        t.download(gW, gH)
+        t.close()
+        out.append((gW, gH))
+    assert _close(out[0][0], W, 1e-4) and _close(out[0][1], H, 1e-4)
+    assert (out[0][0][0] == 0).all()                                    # the empty row (wmf.pyx:154-156)
+    assert _close(out[0][0], out[1][0], 5e-5) and _close(out[0][1], out[1][1], 5e-5)
+
+
 @pytest.mark.parametrize("K,dtype", [(64, "float32"), (128, "float32"), (20, "float64")])
 def test_wmf_row_shards_reproduce_the_single_gpu_sweep(K, dtype, monkeypatch):
     """Multi-GPU row sharding without the collective: three handles act as ranks 0..2 of 3 (test hook
