@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wm
                                                              const int32_t *__restrict__ indices, float *__restrict__ X,
                                                              const float *__restrict__ Y, const float *__restrict__ A0,
                                                              float weight, int32_t long_threshold, int probe,
-                                                             const int32_t *__restrict__ order) {
+                                                             const int32_t *__restrict__ order, const float *__restrict__ A0t) {
     constexpr int K = 32 * T32;
     constexpr int NT = T32 * (T32 + 1) / 2;
     extern __shared__ unsigned char smem_raw[];
@@ -568,15 +568,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wm
 #pragma unroll
         for (int m = 0; m < T32; ++m) bsum[m] = 0.0f;
         {
-            int a0off = 4 * lh * K + li;                         // this lane's corner of every tile; the rest are constants
-            asm volatile("" : "+v"(a0off));                      // per row: 160 hoisted address pairs would live in scratch
-            const float *a0l = A0 + a0off;
+            // the accumulators start from A0 / (w - 1) in the tile layout of wmf_tile_layout_kernel: four 16-byte loads per tile
+            using f4 = __attribute__((ext_vector_type(4))) float;
+            int a0off = lane * 4;
+            asm volatile("" : "+v"(a0off));
+            const f4 *a0t = reinterpret_cast<const f4 *>(A0t) + a0off;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (wave == t % NW) {                            // each tile of A0 enters the sum once; the waves share the loads
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[t][r] = a0l[(32 * tile_m(t) + (r & 3) + 8 * (r >> 2)) * K + 32 * tile_n(t)] * inv_w1;
+                    for (int q = 0; q < 4; ++q) {
+                        const f4 v = a0t[t * 256 + q];
+                        acc[t][4 * q] = v[0]; acc[t][4 * q + 1] = v[1]; acc[t][4 * q + 2] = v[2]; acc[t][4 * q + 3] = v[3];
+                    }
                 } else {
                     acc[t] = (f32x16)(0.0f);
                 }
@@ -638,6 +642,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wm
         } else {
             // 64 gathered rows per batch; each of the T32 32-column chunks of a gathered row is loaded once per
             // step and feeds every tile that uses it (tile (m, n) multiplies chunk m by chunk n)
+            // (one 32-bit byte offset per gathered row, chunk offsets as immediates, unconditional loads selected afterwards, no MFMAs
+            // past the row's end: as in wmf_row_blk_kernel; the host sends tables beyond 4 GB to the older kernels)
+            const char *Yb = reinterpret_cast<const char *>(Y);
             for (int32_t pb = p0; pb < p1; pb += 64) {
                 const int32_t myp = pb + lane;
                 const int32_t myidx = myp < p1 ? indices[myp] : -1;
@@ -645,21 +652,26 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wm
                 const int steps = (nb + 1) >> 1;
                 for (int s0 = wave; s0 < steps; s0 += 8 * NW) {     // steps wave, wave + NW, ... (at most 32 per batch)
                     float ch[8][T32];
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int32_t idx = __shfl(myidx, 2 * (s0 + NW * u) + lh, 64);
                         const bool ok = idx >= 0 && s0 + NW * u < steps;
-                        const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
-    #pragma unroll
-                        for (int m = 0; m < T32; ++m) ch[u][m] = ok ? yrow[32 * m + li] : 0.0f;
+                        const uint32_t off = (uint32_t)(ok ? idx : 0) * (uint32_t)(K * 4) + (uint32_t)(li * 4);
+#pragma unroll
+                        for (int m = 0; m < T32; ++m) {
+                            const float v = *reinterpret_cast<const float *>(Yb + off + 128 * m);
+                            ch[u][m] = ok ? v : 0.0f;
+                        }
                     }
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < 8; ++u) {
-    #pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
-    #pragma unroll
-                        for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
+                        if (s0 + NW * u < steps) {                  // (uniform)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
+#pragma unroll
+                            for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
+                        }
                     }
                 }
             }
@@ -1461,13 +1473,15 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
         else if (nseg > 0)                                                                                                  \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, my_rows, \
                                ip, ix, Xf, Yf, Gf, (float)h->weight, h->long_threshold, segs, nseg, h->d_scratch.p);        \
-        if (my_rows <= 0) {                                                                                                 \
-        } else if (reg_ok && h->weight != 1.0 && (h->blocked >= 0 ? h->blocked != 0 : (T32_) >= 3)) {                      \
-            const int grid_b = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
+        if (my_rows > 0 && reg_ok && h->weight != 1.0) {   /* A0 / (w - 1) in the accumulator tile layout for the one-row kernels */ \
             constexpr int n_a0t = (T32_) * ((T32_) + 1) / 2 * 1024;                                                         \
             CYMF_TRY(h->d_a0t.alloc(n_a0t));                                                                                \
             hipLaunchKernelGGL((wmf_tile_layout_kernel<T32_>), dim3(n_a0t / 256), dim3(256), 0, h->stream, Gf,               \
                                (float)(1.0 / (h->weight - 1.0)), h->d_a0t.p);                                               \
+        }                                                                                                                   \
+        if (my_rows <= 0) {                                                                                                 \
+        } else if (reg_ok && h->weight != 1.0 && (h->blocked >= 0 ? h->blocked != 0 : (T32_) >= 3)) {                      \
+            const int grid_b = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
             hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), (T32_) == 4 ? 16384 : 0, h->stream, n_work, ip, ix, Xf, Yf, h->d_a0t.p, \
                                (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_ticks.p);         \
         } else if (reg_ok && h->weight != 1.0) {                                                                           \
@@ -1477,11 +1491,11 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             if (h->prefetch) {                                                                                              \
                 CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_, true>, smem_r));                                           \
                 hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_, true>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,   \
-                                   n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order); \
+                                   n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_a0t.p); \
             } else {                                                                                                        \
                 CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_, false>, smem_r));                                          \
                 hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_, false>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,  \
-                                   n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order); \
+                                   n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_a0t.p); \
             }                                                                                                               \
         } else {                                                                                                            \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, false>), dim3(grid), dim3(WMF_THREADS), smem, h->stream, my_rows, ip, \
