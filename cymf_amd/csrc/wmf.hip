@@ -1343,6 +1343,8 @@ struct cymf_wmf {
     int dtype = 0, device = 0;
     double weight = 10.0, wd = 0.01;
     hipStream_t stream = nullptr;
+    hipStream_t seg_stream = nullptr;       // the long rows' segments run beside the whole rows (CYMF_WMF_SEG_STREAM=0: on `stream`)
+    hipEvent_t ev_ready = nullptr, ev_segs = nullptr;
     WmfStore<float> f32;
     WmfStore<double> f64;
     DevBuf<int32_t> d_indptr, d_indices, d_tindptr, d_tindices;
@@ -1458,7 +1460,14 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             const float *Gf = reinterpret_cast<const float *>(st.G.p);
             const int32_t nseg = h->n_segs[side], nlong = h->n_long[side];
             const WmfSeg *segs = h->d_segs[side].p;
-            if (nlong > 0) CYMF_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)nlong * ((size_t)K * K + K) * sizeof(float), h->stream));
+            // The long rows' segments and the whole rows are independent until the long rows are finished: the segments go to a
+            // second stream, so that the two kernels' workgroups mix on the CUs and only one tail is paid.
+            hipStream_t ss = (h->seg_stream && reg_ok && nseg > 0) ? h->seg_stream : h->stream;
+            if (ss != h->stream) {
+                CYMF_HIP(hipEventRecord(h->ev_ready, h->stream));   // YtY + lambda I is complete, the previous sweep's table too
+                CYMF_HIP(hipStreamWaitEvent(ss, h->ev_ready, 0));
+            }
+            if (nlong > 0) CYMF_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)nlong * ((size_t)K * K + K) * sizeof(float), ss));
             const int grid_seg = (int)std::min<int64_t>(nseg, 256 * 16);
             const bool sorted = h->row_order && h->d_order[side].p;
             const int32_t *order = sorted ? h->d_order[side].p : nullptr;
@@ -1468,7 +1477,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, false>, smem));                                                        \
         CYMF_TRY(allow_lds(wmf_row_mfma_kernel<T32_, true>, smem));                                                         \
         if (nseg > 0 && reg_ok)   /* segments of the long rows first: the longest work starts earliest */                   \
-            hipLaunchKernelGGL((wmf_seg_kernel<T32_>), dim3(grid_seg), dim3(WMF_THREADS), 0, h->stream, ix, Yf, segs, nseg,  \
+            hipLaunchKernelGGL((wmf_seg_kernel<T32_>), dim3(grid_seg), dim3(WMF_THREADS), 0, ss, ix, Yf, segs, nseg,         \
                                h->d_scratch.p);                                                                             \
         else if (nseg > 0)                                                                                                  \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, true>), dim3(grid_seg), dim3(WMF_THREADS), smem, h->stream, my_rows, \
@@ -1509,6 +1518,10 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             default: WMF_LAUNCH_(4); break;
             }
 #undef WMF_LAUNCH_
+            if (ss != h->stream) {
+                CYMF_HIP(hipEventRecord(h->ev_segs, ss));
+                CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_segs, 0));
+            }
             if (nlong > 0 && reg_ok) {
 #define WMF_FINISH_(T32_)                                                                                                   \
     do {                                                                                                                    \
@@ -1584,6 +1597,15 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     if (const char *e3 = getenv("CYMF_WMF_SEG")) h->seg_len = std::max(64, atoi(e3));
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    const char *e9 = getenv("CYMF_WMF_SEG_STREAM");
+    if (!(e9 && e9[0] == '0')) {
+        if (hipStreamCreateWithFlags(&h->seg_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_segs, hipEventDisableTiming) != hipSuccess) {
+            cymf_wmf_destroy(h);
+            return fail(CYMF_ERR_HIP, "cymf_wmf_create: side stream");
+        }
+    }
     *out = h;
     return 0;
 }
@@ -1741,7 +1763,10 @@ extern "C" int cymf_wmf_epochs(cymf_wmf *h, int32_t n_epochs) {
 extern "C" int cymf_wmf_destroy(cymf_wmf *h) {
     if (!h) return 0;
     if (!cymf::runtime_alive(h->device)) return 0;   // process exit / runtime already torn down: leak quietly
+    if (h->seg_stream) { (void)hipStreamSynchronize(h->seg_stream); (void)hipStreamDestroy(h->seg_stream); }
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+    if (h->ev_segs) (void)hipEventDestroy(h->ev_segs);
     delete h;
     return 0;
 }
