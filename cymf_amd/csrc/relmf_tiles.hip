@@ -291,7 +291,11 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     const int row = lane >> 4, l16 = lane & 15;
     const int n_workers = n_waves * 4, worker = wave * 4 + row;
     const int lane_off = 4 * l16;
-    float loss_u = 0.0f, pl_acc = 0.0f;
+    float loss_u = 0.0f;
+    using f2 = __attribute__((ext_vector_type(2))) float;
+    f2 pl_acc2[EPL / 2];                                         // l2 term of all draws, one packed accumulator per register pair
+#pragma unroll
+    for (int pr = 0; pr < EPL / 2; ++pr) pl_acc2[pr] = f2{0.0f, 0.0f};
     struct UserRegs { float w[EPL], w0[EPL], w1[EPL]; int ul; uint32_t cw; };
     auto fetch_user = [&](int ul, UserRegs &g) {
         const bool ok = ul < nu;
@@ -397,7 +401,11 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
             if (act) {
                 const int il = cur.il;
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) pl_acc += cu.w[e] * cu.w[e] + cur.h[e] * cur.h[e];   // l2 term of all draws, reduced once at the end
+                for (int pr = 0; pr < EPL / 2; ++pr) {           // l2 term of all draws, reduced once at the end: pairs as they lie in
+                    const f2 wv2 = {cu.w[2 * pr], cu.w[2 * pr + 1]}, hv2 = {cur.h[2 * pr], cur.h[2 * pr + 1]};   // the registers, or the packing moves cost more than the FMAs
+                    pl_acc2[pr] = __builtin_elementwise_fma(wv2, wv2, pl_acc2[pr]);
+                    pl_acc2[pr] = __builtin_elementwise_fma(hv2, hv2, pl_acc2[pr]);
+                }
                 // q (1 - y)^2 + (1 - q) y^2 = q + y (y - 2 q)   (cymf/model.pyx:117; the 16 lanes of the row hold the same draw:
                 // the sum is divided by 16 at the end);   q (1 - y) + (1 - q)(0 - y) = q - y   (cymf/model.pyx:131-139, no factor 2)
                 const float q = cur.q;
@@ -478,6 +486,9 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
             if constexpr (NS == 2) d.p.H1[g] = ss1[e];
         }
     }
+    float pl_acc = 0.0f;
+#pragma unroll
+    for (int pr = 0; pr < EPL / 2; ++pr) pl_acc += pl_acc2[pr][0] + pl_acc2[pr][1];
     const float l2 = wave_sum(pl_acc), lu = wave_sum(loss_u) * (1.0f / 16.0f);
     if (lane == 0) atomicAdd(loss_acc, (double)(lu + d.p.wd * l2));
     stamp(5);
