@@ -15,6 +15,7 @@ struct RelTilePlan {
     int32_t ib = 0;       // items per block  (<= 64: one lane per item of the block)
     int32_t R = 0;        // row elements per lane, K <= 64 R
     int32_t threads = 0;  // workgroup size of the tile kernel
+    int32_t lpd = 16;     // lanes per draw: 16 (four elements per lane and 64-element block) or 8 (eight)
     int64_t N = 0;        // draws per epoch = U * I
     size_t lds_bytes = 0;
 };

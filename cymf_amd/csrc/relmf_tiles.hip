@@ -190,18 +190,20 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
-__device__ __forceinline__ uint32_t row_or(uint32_t v) {   // OR over the 16 lanes of the DPP row, in every lane of the row
+template <int LPD>
+__device__ __forceinline__ uint32_t row_or(uint32_t v) {   // OR over the LPD (16 or 8) lanes of a worker, in every lane of it
     v |= dpp_u32<DPP_QUAD_PERM_1032>(v);
     v |= dpp_u32<DPP_QUAD_PERM_2301>(v);
     v |= dpp_u32<DPP_ROW_HALF_MIRROR>(v);
-    v |= dpp_u32<DPP_ROW_MIRROR>(v);
+    if constexpr (LPD == 16) v |= dpp_u32<DPP_ROW_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ float row_sum(float v) {        // sum over the 16 lanes of the DPP row, in every lane of the row
+template <int LPD>
+__device__ __forceinline__ float row_sum(float v) {        // sum over the LPD lanes of a worker, in every lane of it
     v += dpp_f32<DPP_QUAD_PERM_1032>(v);
     v += dpp_f32<DPP_QUAD_PERM_2301>(v);
     v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);
-    v += dpp_f32<DPP_ROW_MIRROR>(v);
+    if constexpr (LPD == 16) v += dpp_f32<DPP_ROW_MIRROR>(v);
     return v;
 }
 __device__ __forceinline__ unsigned long long pack2(float a, float b) {
@@ -224,14 +226,17 @@ __device__ __forceinline__ unsigned long long pack2(float a, float b) {
 //      copy forces the wait early); a draw's compare-and-swaps are checked after the next draw's dot product.
 //      Lanes past K compute on zeros inside the rows' padding (no masking in the loop).
 //   4. the item rows go back to HBM once.
-template <int R, int OPT, int MAXT>
+template <int R, int OPT, int MAXT, int LPD>
 __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const uint32_t *__restrict__ sorted,
                                                         const uint32_t *__restrict__ toff, int shift,
                                                         double *__restrict__ loss_acc, int *__restrict__ err,
                                                         long long *__restrict__ stamps) {
     constexpr int NS = opt_num_states(OPT);
     constexpr int RS = R * 64;                       // LDS row stride (floats)
-    constexpr int EPL = 4 * R;                       // row elements per lane
+    constexpr int CH = 64 / LPD;                     // consecutive row elements per lane and 64-element block (4: one b128, 8: two)
+    constexpr int EPL = CH * R;                      // row elements per lane
+    constexpr int WPW = 64 / LPD;                    // workers per wavefront
+    constexpr int WPL = CH / 4;                      // words of byte counters per lane (CH items per lane)
     constexpr float SFILL = OPT == CYMF_OPT_ADAGRAD ? 1.0f : 0.0f;   // lanes past K of state rows (rows.h: Row::load)
     extern __shared__ unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, n_waves = nthreads >> 6;
@@ -279,8 +284,9 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
         const uint32_t u = c / I, i = c - u * I;
         const uint32_t ul = u - (uint32_t)u0, il = i - (uint32_t)i0;
         if (ul < (uint32_t)nu && il < (uint32_t)ni) {
-            const uint32_t old = atomicAdd(&s_cc[ul * 16 + (il & 15)], 1u << (8 * (il >> 4)));
-            if (((old >> (8 * (il >> 4))) & 255u) == 255u) atomicExch(err, 2);   // counter overflow: never with uniform draws
+            const uint32_t slot = il / LPD;              // item il: lane il % LPD of a worker, its slot-th counter
+            const uint32_t old = atomicAdd(&s_cc[ul * 16 + (il % LPD) * WPL + (slot >> 2)], 1u << (8 * (slot & 3)));
+            if (((old >> (8 * (slot & 3))) & 255u) == 255u) atomicExch(err, 2);   // counter overflow: never with uniform draws
         } else {
             atomicExch(err, 1);   // a cell outside its tile: broken bucketing must not become a wild LDS access
         }
@@ -288,23 +294,24 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     __syncthreads();
     stamp(1);
 
-    const int row = lane >> 4, l16 = lane & 15;
-    const int n_workers = n_waves * 4, worker = wave * 4 + row;
-    const int lane_off = 4 * l16;
+    const int row = lane / LPD, l16 = lane % LPD;    // (l16: the lane's index inside its worker, 0 .. LPD-1)
+    const int n_workers = n_waves * WPW, worker = wave * WPW + row;
+    const int lane_off = CH * l16;
     float loss_u = 0.0f;
     using f2 = __attribute__((ext_vector_type(2))) float;
     f2 pl_acc2[EPL / 2];                                         // l2 term of all draws, one packed accumulator per register pair
 #pragma unroll
     for (int pr = 0; pr < EPL / 2; ++pr) pl_acc2[pr] = f2{0.0f, 0.0f};
-    struct UserRegs { float w[EPL], w0[EPL], w1[EPL]; int ul; uint32_t cw; };
+    struct UserRegs { float w[EPL], w0[EPL], w1[EPL]; int ul; uint32_t cw[WPL]; };
     auto fetch_user = [&](int ul, UserRegs &g) {
         const bool ok = ul < nu;
         g.ul = ok ? ul : 0;
-        g.cw = ok ? s_cc[ul * 16 + l16] : 0u;
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) g.cw[q] = ok ? s_cc[ul * 16 + l16 * WPL + q] : 0u;
         const int64_t base = ((int64_t)u0 + g.ul) * K;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const int k = 64 * (e >> 2) + 4 * l16 + (e & 3);
+            const int k = 64 * (e / CH) + CH * l16 + (e % CH);
             const bool in = ok && k < K;
             g.w[e] = in ? d.p.W[base + k] : 0.0f;
             g.w0[e] = (NS >= 1 && in) ? d.p.W0[base + k] : SFILL;
@@ -318,7 +325,10 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     for (int round = 0; round * n_workers < nu; ++round) {
         UserRegs cu = nxt;
         fetch_user(worker + (round + 1) * n_workers, nxt);
-        const bool had_draws = row_or(cu.cw) != 0u;
+        uint32_t any_cw = cu.cw[0];
+#pragma unroll
+        for (int q = 1; q < WPL; ++q) any_cw |= cu.cw[q];
+        const bool had_draws = row_or<LPD>(any_cw) != 0u;
         // items of this user with count >= c, as a 64-bit mask held by every lane of the row.  The mask is walked from a
         // user-specific rotation: workers that all started at item 0 would meet on the same item rows at the same time
         // (measured with Adam, whose steps do not shrink with the gradient: norm of H +19 % against the sequential order).
@@ -327,9 +337,15 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
         unsigned long long mask = 0ull;
         auto next_mask = [&]() {
             ++pass;
-            const uint32_t b0 = (cu.cw & 255u) >= pass, b1 = ((cu.cw >> 8) & 255u) >= pass, b2 = ((cu.cw >> 16) & 255u) >= pass,
-                           b3 = (cu.cw >> 24) >= pass;
-            const uint32_t lo = row_or((b0 << l16) | (b1 << (16 + l16))), hi = row_or((b2 << l16) | (b3 << (16 + l16)));
+            // counter `slot` of lane l is item slot * LPD + l = bit slot * LPD + l of the mask
+            uint32_t lo_bits = 0u, hi_bits = 0u;
+#pragma unroll
+            for (int slot = 0; slot < CH; ++slot) {
+                const uint32_t bit = ((cu.cw[slot >> 2] >> (8 * (slot & 3))) & 255u) >= pass;
+                if (slot * LPD < 32) lo_bits |= bit << (slot * LPD + l16);
+                else hi_bits |= bit << (slot * LPD - 32 + l16);
+            }
+            const uint32_t lo = row_or<LPD>(lo_bits), hi = row_or<LPD>(hi_bits);
             const unsigned long long m = ((unsigned long long)hi << 32) | lo;    // bit il
             mask = rot ? (m >> rot) | (m << (64 - rot)) : m;                      // bit (il - rot) mod 64
         };
@@ -348,17 +364,18 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
             const int a = il < 0 ? 0 : il;
             g.q = s_q[cu.ul * d.ib + a];
 #pragma unroll
-            for (int jj = 0; jj < R; ++jj) {
-                const float4 v = *reinterpret_cast<const float4 *>(sh + a * RS + 64 * jj + lane_off);
-                g.h[4 * jj] = v.x; g.h[4 * jj + 1] = v.y; g.h[4 * jj + 2] = v.z; g.h[4 * jj + 3] = v.w;
-                if constexpr (NS >= 1) { const float4 s4 = *reinterpret_cast<const float4 *>(ss0 + a * RS + 64 * jj + lane_off); g.t0[4 * jj] = s4.x; g.t0[4 * jj + 1] = s4.y; g.t0[4 * jj + 2] = s4.z; g.t0[4 * jj + 3] = s4.w; }
-                if constexpr (NS == 2) { const float4 s4 = *reinterpret_cast<const float4 *>(ss1 + a * RS + 64 * jj + lane_off); g.t1[4 * jj] = s4.x; g.t1[4 * jj + 1] = s4.y; g.t1[4 * jj + 2] = s4.z; g.t1[4 * jj + 3] = s4.w; }
+            for (int jv = 0; jv < R * WPL; ++jv) {               // jv: float4 number jv % WPL of block jv / WPL
+                const int off = a * RS + 64 * (jv / WPL) + lane_off + 4 * (jv % WPL), e = 4 * jv;
+                const float4 v = *reinterpret_cast<const float4 *>(sh + off);
+                g.h[e] = v.x; g.h[e + 1] = v.y; g.h[e + 2] = v.z; g.h[e + 3] = v.w;
+                if constexpr (NS >= 1) { const float4 s4 = *reinterpret_cast<const float4 *>(ss0 + off); g.t0[e] = s4.x; g.t0[e + 1] = s4.y; g.t0[e + 2] = s4.z; g.t0[e + 3] = s4.w; }
+                if constexpr (NS == 2) { const float4 s4 = *reinterpret_cast<const float4 *>(ss1 + off); g.t1[e] = s4.x; g.t1[e + 1] = s4.y; g.t1[e + 2] = s4.z; g.t1[e + 3] = s4.w; }
             }
         };
         // the previous draw's pending compare-and-swaps: pairs of row words (and of AdaGrad's accumulator words)
         bool pend = false;
         int p_il = 0;
-        unsigned long long p_old[2 * R], p_seen[2 * R], a_old[2 * R], a_seen[2 * R];
+        unsigned long long p_old[EPL / 2], p_seen[EPL / 2], a_old[EPL / 2], a_seen[EPL / 2];
         float p_dlt[EPL], a_dlt[EPL];
         auto settle = [&]() {
             // Adam: a swap that failed is NOT retried.  Its step does not shrink with the gradient, so two workers that formed
@@ -367,8 +384,8 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
             // +8 % without; loss +0.6 % / +0.2 %).  The row keeps the other worker's step.
             if (pend && OPT != CYMF_OPT_ADAM) {
 #pragma unroll
-                for (int pr = 0; pr < 2 * R; ++pr) {
-                    const int e0 = 2 * pr, loc = p_il * RS + 64 * (pr >> 1) + lane_off + 2 * (pr & 1);
+                for (int pr = 0; pr < EPL / 2; ++pr) {
+                    const int e0 = 2 * pr, loc = p_il * RS + 64 * (e0 / CH) + lane_off + (e0 % CH);
                     unsigned long long *a = reinterpret_cast<unsigned long long *>(sh + loc);
                     unsigned long long old = p_old[pr], seen = p_seen[pr];
                     while (seen != old) {      // somebody else updated the words meanwhile: add the deltas to what is there now
@@ -395,7 +412,7 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
             float py = 0.0f;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) py += cu.w[e] * cur.h[e];
-            float y = row_sum(py);
+            float y = row_sum<LPD>(py);
             if (pend) asm volatile("" : "+v"(p_seen[0]), "+v"(y));   // keeps the wait for the previous draw's swaps behind this dot product
             settle();
             if (act) {
@@ -406,8 +423,8 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
                     pl_acc2[pr] = __builtin_elementwise_fma(wv2, wv2, pl_acc2[pr]);
                     pl_acc2[pr] = __builtin_elementwise_fma(hv2, hv2, pl_acc2[pr]);
                 }
-                // q (1 - y)^2 + (1 - q) y^2 = q + y (y - 2 q)   (cymf/model.pyx:117; the 16 lanes of the row hold the same draw:
-                // the sum is divided by 16 at the end);   q (1 - y) + (1 - q)(0 - y) = q - y   (cymf/model.pyx:131-139, no factor 2)
+                // q (1 - y)^2 + (1 - q) y^2 = q + y (y - 2 q)   (cymf/model.pyx:117; the LPD lanes of the worker hold the same draw:
+                // the sum is divided by LPD at the end);   q (1 - y) + (1 - q)(0 - y) = q - y   (cymf/model.pyx:131-139, no factor 2)
                 const float q = cur.q;
                 loss_u += fmaf(y, fmaf(-2.0f, q, y), q);
                 const float c = q - y;
@@ -424,8 +441,8 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
                 // AdaGrad's accumulator is a sum of g^2: added losslessly like the row; Adam's moments are not additive and
                 // are stored as this worker's consistent pair (as in the other lock-free kernels)
 #pragma unroll
-                for (int pr = 0; pr < 2 * R; ++pr) {
-                    const int e0 = 2 * pr, loc = il * RS + 64 * (pr >> 1) + lane_off + 2 * (pr & 1);
+                for (int pr = 0; pr < EPL / 2; ++pr) {
+                    const int e0 = 2 * pr, loc = il * RS + 64 * (e0 / CH) + lane_off + (e0 % CH);
                     p_old[pr] = pack2(cur.h[e0], cur.h[e0 + 1]);
                     p_dlt[e0] = hnew[e0] - cur.h[e0]; p_dlt[e0 + 1] = hnew[e0 + 1] - cur.h[e0 + 1];
                     p_seen[pr] = atomicCAS(reinterpret_cast<unsigned long long *>(sh + loc), p_old[pr], pack2(hnew[e0], hnew[e0 + 1]));
@@ -465,7 +482,7 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
             const int64_t base = ((int64_t)u0 + cu.ul) * K;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
-                const int k = 64 * (e >> 2) + 4 * l16 + (e & 3);
+                const int k = 64 * (e / CH) + CH * l16 + (e % CH);
                 if (k < K) {
                     d.p.W[base + k] = cu.w[e];
                     if constexpr (NS >= 1) d.p.W0[base + k] = cu.w0[e];
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     float pl_acc = 0.0f;
 #pragma unroll
     for (int pr = 0; pr < EPL / 2; ++pr) pl_acc += pl_acc2[pr][0] + pl_acc2[pr][1];
-    const float l2 = wave_sum(pl_acc), lu = wave_sum(loss_u) * (1.0f / 16.0f);
+    const float l2 = wave_sum(pl_acc), lu = wave_sum(loss_u) * (1.0f / (float)LPD);
     if (lane == 0) atomicAdd(loss_acc, (double)(lu + d.p.wd * l2));
     stamp(5);
 }
@@ -509,20 +526,29 @@ int allow_lds(F kernel, size_t bytes) {
 template <int R>
 int launch_tile(const RelTilePlan &p, const RelTileDev &d, const uint32_t *sorted, const uint32_t *toff, int shift, double *loss,
                 int *err, long long *stamps, hipStream_t s) {
+#define TILE_L_(O_, MAXT_, LPD_)                                                                                        \
+    do {                                                                                                                \
+        CYMF_TRY(allow_lds(relmf_tile_kernel<R, O_, MAXT_, LPD_>, p.lds_bytes));                                        \
+        hipLaunchKernelGGL((relmf_tile_kernel<R, O_, MAXT_, LPD_>), dim3(p.B), dim3(p.threads), p.lds_bytes, s, d, sorted, toff, shift, loss, err, stamps); \
+    } while (0)
 #define TILE_(O_)                                                                                                       \
     do {                                                                                                                \
-        if (p.threads > 512) {   /* up to 16 wavefronts: the 128-VGPR build */                                          \
-            CYMF_TRY(allow_lds(relmf_tile_kernel<R, O_, 1024>, p.lds_bytes));                                           \
-            hipLaunchKernelGGL((relmf_tile_kernel<R, O_, 1024>), dim3(p.B), dim3(p.threads), p.lds_bytes, s, d, sorted, toff, shift, loss, err, stamps); \
-        } else {                                                                                                        \
-            CYMF_TRY(allow_lds(relmf_tile_kernel<R, O_, 512>, p.lds_bytes));                                            \
-            hipLaunchKernelGGL((relmf_tile_kernel<R, O_, 512>), dim3(p.B), dim3(p.threads), p.lds_bytes, s, d, sorted, toff, shift, loss, err, stamps); \
+        if constexpr (R == 1) {                                                                                         \
+            if (p.lpd == 8) {   /* eight lanes per draw, eight elements per lane */                                     \
+                if (p.threads > 768) TILE_L_(O_, 1024, 8);                                                              \
+                else if (p.threads > 512) TILE_L_(O_, 768, 8);                                                          \
+                else TILE_L_(O_, 512, 8);                                                                               \
+                break;                                                                                                  \
+            }                                                                                                           \
         }                                                                                                               \
+        if (p.threads > 512) TILE_L_(O_, 1024, 16);   /* up to 16 wavefronts: the 128-VGPR build */                     \
+        else TILE_L_(O_, 512, 16);                                                                                      \
     } while (0)
     if (p.opt == CYMF_OPT_SGD) TILE_(CYMF_OPT_SGD);
     else if (p.opt == CYMF_OPT_ADAGRAD) TILE_(CYMF_OPT_ADAGRAD);
     else TILE_(CYMF_OPT_ADAM);
 #undef TILE_
+#undef TILE_L_
     return 0;
 }
 
@@ -553,11 +579,21 @@ bool relmf_tile_plan(int32_t U, int32_t I, int32_t K, int opt, RelTilePlan *plan
     // VGPRs -- a worker holds its user's row and state, two draws' item rows and the pending swaps); the users of a block
     // are dealt round-robin, so pick the count that leaves the fewest workers idle in the last round, preferring two
     // wavefronts per SIMD
+    // Lanes per draw: 16 with four row elements each.  Eight lanes with eight elements (K <= 64; CYMF_RELMF_TILE_LPD=8) share a
+    // step's bookkeeping (next item, pending swaps, masks, branches: ~3/4 of its instructions) between eight draws instead
+    // of four and were expected to be faster; measured on 20000 x 8000, K = 64: 30.8 against 25.6 ms per epoch (SGD), 41 against
+    // 34 (AdaGrad) -- the 80 users of a block then need ten wavefronts instead of sixteen, and a step is a latency chain
+    // (LDS read -> dot -> DPP sum -> swap) that the fewer wavefronts hide less well.  Kept as a tested variant.
+    p.lpd = 16;
+    if (const char *el = getenv("CYMF_RELMF_TILE_LPD")) p.lpd = (atoi(el) == 8 && p.R == 1) ? 8 : 16;   // developer
+    const int wpw = 64 / p.lpd;
     int best_nw = 4;
     double best = -1.0;
-    const int nw_max = p.R == 1 ? 16 : 8;   // 16: the 1024-thread build (128 VGPRs) holds K <= 64 without spilling
+    // 16: the 1024-thread build (128 VGPRs) holds K <= 64 without spilling; eight lanes per draw with AdaGrad / Adam state: 12 (the
+    // 768-thread build, 168 VGPRs)
+    const int nw_max = p.R == 1 ? ((p.lpd == 8 && opt != CYMF_OPT_SGD) ? 12 : 16) : 8;
     for (int nw = 4; nw <= nw_max; ++nw) {
-        const int workers = 4 * nw, rounds = (p.ub + workers - 1) / workers;
+        const int workers = wpw * nw, rounds = (p.ub + workers - 1) / workers;
         // fewer idle workers in the last round is worth as much as more wavefronts to hide latencies (measured on 20000 x 8000,
         // K = 64: 7 / 14 / 16 wavefronts 32.0 / 30.3 / 30.8 ms per epoch)
         const double eff = (double)p.ub / ((double)rounds * workers) * (0.6 + 0.4 * std::min(nw, 14) / 14.0);
