@@ -529,8 +529,8 @@ __device__ __forceinline__ void stage_rounds(f32x2 (&a)[16 * T32], const f32x16 
 // its share of the gathered rows; the tiles go through a small LDS stage to turn the MFMA C layout into "lane j holds row j"
 // (rows read the tile, the mirrored block reads its transpose), and the system is solved in registers.  Little LDS and
 // <= 168 VGPRs at K <= 64 on purpose: the column steps are a latency chain, three waves per SIMD fill it.
-template <int T32, int NW, bool PRE>
-__global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wmf_row_reg_kernel(int32_t rows, const int32_t *__restrict__ indptr,
+template <int T32, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(int32_t rows, const int32_t *__restrict__ indptr,
                                                              const int32_t *__restrict__ indices, float *__restrict__ X,
                                                              const float *__restrict__ Y, const float *__restrict__ A0,
                                                              float weight, int32_t long_threshold, int probe,
@@ -588,90 +588,37 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 3 : 2) - (PRE ? 1 : 0)) void wm
         }
         // 64 gathered rows per batch (lane l holds the index of entry l), 32 k=2 steps per batch dealt to the waves in turn, 8 steps
         // per group: each of the T32 32-column chunks of a gathered row is loaded once per step and feeds every tile that uses it
-        // (tile (m, n) multiplies chunk m by chunk n).  The loads of group g + 1 (and the indices of the batch after next) are
-        // issued BEFORE the MFMAs of group g: at K >= 96 one wave per SIMD is resident, so nothing else hides an L2 miss
-        // (without the look-ahead the matrix pipe sat idle for one memory latency per group: 0.27 busy at K=128).
-        if constexpr (PRE) {
-            constexpr int GPB = 4 / NW;                          // groups per batch and wave
-            const int n = p1 - p0;
-            const int n_groups = ((n + 63) >> 6) * GPB;
-            const auto batch_indices = [&](int b) -> int32_t {
-                const int32_t myp = p0 + 64 * b + lane;
-                return myp < p1 ? indices[myp] : -1;
-            };
-            const auto load_group = [&](int g, int32_t idxvec, float (&c)[8][T32]) {
-                const int q = g % GPB;
+        // (tile (m, n) multiplies chunk m by chunk n).  (A variant that issued the loads of group g + 1 before the MFMAs of group g
+        // costs a wave per SIMD in registers and measured slower: K=128 user sweep 13.1 -> 15.9 ms, K=64 unchanged.)
+        // (one 32-bit byte offset per gathered row, chunk offsets as immediates, unconditional loads selected afterwards, no MFMAs
+        // past the row's end: as in wmf_row_blk_kernel; the host sends tables beyond 4 GB to the older kernels)
+        const char *Yb = reinterpret_cast<const char *>(Y);
+        for (int32_t pb = p0; pb < p1; pb += 64) {
+            const int32_t myp = pb + lane;
+            const int32_t myidx = myp < p1 ? indices[myp] : -1;
+            const int nb = p1 - pb < 64 ? p1 - pb : 64;
+            const int steps = (nb + 1) >> 1;
+            for (int s0 = wave; s0 < steps; s0 += 8 * NW) {     // steps wave, wave + NW, ... (at most 32 per batch)
+                float ch[8][T32];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int32_t idx = __shfl(idxvec, 2 * (wave + NW * (8 * q + u)) + lh, 64);
-                    const bool ok = idx >= 0;
-                    const float *yrow = Y + (int64_t)(ok ? idx : 0) * K;
+                    const int32_t idx = __shfl(myidx, 2 * (s0 + NW * u) + lh, 64);
+                    const bool ok = idx >= 0 && s0 + NW * u < steps;
+                    const uint32_t off = (uint32_t)(ok ? idx : 0) * (uint32_t)(K * 4) + (uint32_t)(li * 4);
 #pragma unroll
-                    for (int m = 0; m < T32; ++m) c[u][m] = ok ? yrow[32 * m + li] : 0.0f;
-                }
-            };
-            int32_t idx_cur = batch_indices(0), idx_nxt = n > 64 ? batch_indices(1) : -1;
-            float cur[8][T32], nxt[8][T32];
-            if (n_groups > 0) load_group(0, idx_cur, cur);
-            for (int g = 0; g < n_groups; ++g) {
-                const int gn = g + 1;
-                if (gn < n_groups) {
-                    if (gn % GPB == 0) {
-                        idx_cur = idx_nxt;
-                        idx_nxt = 64 * (gn / GPB + 1) < n ? batch_indices(gn / GPB + 1) : -1;
+                    for (int m = 0; m < T32; ++m) {
+                        const float v = *reinterpret_cast<const float *>(Yb + off + 128 * m);
+                        ch[u][m] = ok ? v : 0.0f;
                     }
-                    load_group(gn, idx_cur, nxt);
                 }
-                const int left = n - 64 * (g / GPB);             // entries of this group's batch
-                const int steps = ((left < 64 ? left : 64) + 1) >> 1;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    if (wave + NW * (8 * (g % GPB) + u) < steps) {   // (uniform) a short last batch issues no MFMAs on zeros
+                    if (s0 + NW * u < steps) {                  // (uniform)
 #pragma unroll
                         for (int t = 0; t < NT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u][tile_m(t)], cur[u][tile_n(t)], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
 #pragma unroll
-                        for (int m = 0; m < T32; ++m) bsum[m] += cur[u][m];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-#pragma unroll
-                    for (int m = 0; m < T32; ++m) cur[u][m] = nxt[u][m];
-            }
-        } else {
-            // 64 gathered rows per batch; each of the T32 32-column chunks of a gathered row is loaded once per
-            // step and feeds every tile that uses it (tile (m, n) multiplies chunk m by chunk n)
-            // (one 32-bit byte offset per gathered row, chunk offsets as immediates, unconditional loads selected afterwards, no MFMAs
-            // past the row's end: as in wmf_row_blk_kernel; the host sends tables beyond 4 GB to the older kernels)
-            const char *Yb = reinterpret_cast<const char *>(Y);
-            for (int32_t pb = p0; pb < p1; pb += 64) {
-                const int32_t myp = pb + lane;
-                const int32_t myidx = myp < p1 ? indices[myp] : -1;
-                const int nb = p1 - pb < 64 ? p1 - pb : 64;
-                const int steps = (nb + 1) >> 1;
-                for (int s0 = wave; s0 < steps; s0 += 8 * NW) {     // steps wave, wave + NW, ... (at most 32 per batch)
-                    float ch[8][T32];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int32_t idx = __shfl(myidx, 2 * (s0 + NW * u) + lh, 64);
-                        const bool ok = idx >= 0 && s0 + NW * u < steps;
-                        const uint32_t off = (uint32_t)(ok ? idx : 0) * (uint32_t)(K * 4) + (uint32_t)(li * 4);
-#pragma unroll
-                        for (int m = 0; m < T32; ++m) {
-                            const float v = *reinterpret_cast<const float *>(Yb + off + 128 * m);
-                            ch[u][m] = ok ? v : 0.0f;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (s0 + NW * u < steps) {                  // (uniform)
-#pragma unroll
-                            for (int t = 0; t < NT; ++t)
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ch[u][tile_m(t)], ch[u][tile_n(t)], acc[t], 0, 0, 0);
-#pragma unroll
-                            for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
-                        }
+                        for (int m = 0; m < T32; ++m) bsum[m] += ch[u][m];
                     }
                 }
             }
@@ -1358,7 +1305,6 @@ struct cymf_wmf {
     int probe = 0;           // CYMF_WMF_PROBE: 1 skips the solve, 2 the Gramian (timing only, results invalid)
     int row_order = 1;       // CYMF_WMF_ROW_ORDER=0: rows in index order instead of longest first
     int blocked = -1;        // CYMF_WMF_BLOCKED: 1/0 force/forbid the blocked elimination (wmf_row_blk_kernel); default: K >= 96
-    int prefetch = 0;        // CYMF_WMF_PREFETCH: look-ahead loads in the row kernel (one wave per SIMD less resident)
     bool reg_solve = true;   // register-resident solve (wmf_row_reg_kernel); CYMF_WMF_LDS_SOLVE=1 selects the in-LDS one
     // rows with more than long_threshold entries are built from segments (MFMA path)
     int32_t long_threshold = 2048;
@@ -1497,15 +1443,9 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             constexpr int NW_ = (T32_) <= 2 ? 1 : 2;                                                                        \
             const size_t smem_r = wmf_reg_smem<T32_, NW_>();                                                                \
             const int grid_r = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
-            if (h->prefetch) {                                                                                              \
-                CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_, true>, smem_r));                                           \
-                hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_, true>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,   \
-                                   n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_a0t.p); \
-            } else {                                                                                                        \
-                CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_, false>, smem_r));                                          \
-                hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_, false>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,  \
-                                   n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_a0t.p); \
-            }                                                                                                               \
+            CYMF_TRY(allow_lds(wmf_row_reg_kernel<T32_, NW_>, smem_r));                                                     \
+            hipLaunchKernelGGL((wmf_row_reg_kernel<T32_, NW_>), dim3(grid_r), dim3(64 * NW_), smem_r, h->stream,             \
+                               n_work, ip, ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, h->probe, order, h->d_a0t.p); \
         } else {                                                                                                            \
             hipLaunchKernelGGL((wmf_row_mfma_kernel<T32_, false>), dim3(grid), dim3(WMF_THREADS), smem, h->stream, my_rows, ip, \
                                ix, Xf, Yf, Gf, (float)h->weight, nlong > 0 ? h->long_threshold : 0, segs, nseg, h->d_scratch.p); \
@@ -1585,7 +1525,6 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     const char *env = getenv("CYMF_WMF_NO_MFMA");
     h->use_mfma = !(env && env[0] == '1');
     if (const char *e4 = getenv("CYMF_WMF_PROBE")) h->probe = atoi(e4);
-    if (const char *e6 = getenv("CYMF_WMF_PREFETCH")) h->prefetch = atoi(e6);
     if (const char *e7 = getenv("CYMF_WMF_BLOCKED")) h->blocked = atoi(e7);
     if (const char *e8 = getenv("CYMF_WMF_ROW_ORDER")) h->row_order = atoi(e8);
     if (const char *e5 = getenv("CYMF_WMF_FAKE_SHARD")) {
