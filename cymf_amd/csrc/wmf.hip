@@ -677,7 +677,9 @@ __global__ void wmf_tile_layout_kernel(const float *__restrict__ A0, float inv_w
 // directly after the VALU instruction that wrote its operand reads stale lanes, and hipcc 7.2 inserts no wait state
 // (tools/micro/permlane.hip: half-wave sums off by one row; one s_nop 0 in front is enough for both).
 __device__ __forceinline__ void swap32_self(float v, float &lo_all, float &hi_all) {
-    asm("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\tv_permlane32_swap_b32 %0, %1" : "=&v"(lo_all), "=&v"(hi_all) : "v"(v));
+    // volatile: the swap must execute with all lanes enabled -- sunk into the not-taken side of a per-half select it would run
+    // under a half-wave exec mask and move nothing
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\tv_permlane32_swap_b32 %0, %1" : "=&v"(lo_all), "=&v"(hi_all) : "v"(v));
 }
 __device__ __forceinline__ float half_bcast(float v, int half) {   // lanes l and l + 32 <- v of lane l + 32 * half
     float lo, hi;
@@ -705,7 +707,7 @@ __device__ __forceinline__ float half_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
     float even, odd;   // {rows 0 0 2 2, rows 1 1 3 3}
-    asm("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\tv_permlane16_swap_b32 %0, %1" : "=&v"(even), "=&v"(odd) : "v"(v));
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 0\n\tv_permlane16_swap_b32 %0, %1" : "=&v"(even), "=&v"(odd) : "v"(v));
     return even + odd;
 }
 
@@ -716,20 +718,32 @@ __device__ __forceinline__ float half_sum(float v) {
 // step:  row C <- row C / sqrt(d),  rows i > C -= U[C][i] * (row C).  U[C][i] is taken from row C of the tile itself: the
 // trailing part is symmetric up to rounding.  Rows <= C are not touched (A operand masked); what the updates write below the
 // diagonal of the tile is never read.
+// Two pivots per MFMA: rows C and C + 1 (C even) lie in registers RC and RC + 1 of the SAME half; row C + 1 takes the update of
+// step C on the VALU (one FMA per tile), and the two rank-1 updates of the rows below go through the matrix unit together --
+// the k=2 instruction has room for two outer products: this half supplies row C, the other half (by v_permlane32_swap) row C + 1.
 template <int C>
 __device__ __forceinline__ void chol_step(f32x16 &D, f32x16 &E, int li, int lh) {
+    static_assert((C & 1) == 0, "pivot pairs start at even rows");
     constexpr int RC = (C & 3) + 4 * (C >> 3), LC = (C >> 2) & 1;
     const bool mine = lh == LC;
-    const float prow = D[RC];
-    const float rs = rsq_nr(lane_value(prow, C + 32 * LC));
-    const float urow = prow * rs;
-    D[RC] = mine ? urow : prow;
-    const float aop = mine && li > C ? -urow : 0.0f;
-    D = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, mine ? urow : 0.0f, D, 0, 0, 0);
-    const float erow = E[RC] * rs;
-    E[RC] = mine ? erow : E[RC];
-    E = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, mine ? erow : 0.0f, E, 0, 0, 0);
-    if constexpr (C + 1 < 32) chol_step<C + 1>(D, E, li, lh);
+    const float p0 = D[RC];
+    const float rs0 = rsq_nr(lane_value(p0, C + 32 * LC));
+    const float u0 = p0 * rs0, e0 = E[RC] * rs0;
+    const float f = lane_value(u0, C + 1 + 32 * LC);            // U[C][C+1]
+    const float p1 = __builtin_fmaf(-f, u0, D[RC + 1]);
+    const float rs1 = rsq_nr(lane_value(p1, C + 1 + 32 * LC));
+    const float u1 = p1 * rs1, e1 = __builtin_fmaf(-f, e0, E[RC + 1]) * rs1;
+    D[RC] = mine ? u0 : D[RC];
+    D[RC + 1] = mine ? u1 : D[RC + 1];
+    E[RC] = mine ? e0 : E[RC];
+    E[RC + 1] = mine ? e1 : E[RC + 1];
+    const float u1o = other_half(u1, lh), e1o = other_half(e1, lh);   // (all lanes: see swap32_self)
+    const float ub = mine ? u0 : u1o;                           // B operand: row C in half LC, row C + 1 in the other half
+    const float eb = mine ? e0 : e1o;
+    const float aop = li > C + 1 ? -ub : 0.0f;                  // rows below the pair only
+    D = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, ub, D, 0, 0, 0);
+    E = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, eb, E, 0, 0, 0);
+    if constexpr (C + 2 < 32) chol_step<C + 2>(D, E, li, lh);
 }
 
 // value of lane-layout vector v (element j in lanes j and j + 32) at this lane's row of register r
