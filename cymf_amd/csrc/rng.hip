@@ -437,6 +437,10 @@ int DeviceRng::init(uint32_t seed, uint64_t range, hipStream_t s, bool parallel)
 }
 
 int DeviceRng::ensure_states(int64_t last_chunk, hipStream_t s) {
+    // A launch of the widest level costs the same ~0.45 ms for one state as for 256 (one workgroup per CU): once that level is
+    // available the run is always extended to the next multiple of 256 states, so that an epoch of n chunks costs n / 256
+    // launches instead of one or two partial ones per call (RelMF 20000 x 8000: 635 chunks per epoch, 5 launches -> 2.5).
+    if (states_known_ >= 256) last_chunk = ((last_chunk + 256) / 256) * 256 - 1;
     if (last_chunk + 1 > states_cap_) {
         int64_t cap = states_cap_;
         while (cap < last_chunk + 1) cap *= 2;
