@@ -29,10 +29,18 @@ struct Row {
 #pragma unroll
             for (int r = 0; r < R; ++r) v[r] = t.x[r];
         } else {
+            // R = ceil(K / 64): every element but the last of a lane exists whatever the lane, only r = R - 1 is masked; its
+            // load is unconditional from a clamped index and selected afterwards (a branch per element otherwise: the GloVe
+            // step kernel at K = 100 spent a tenth of its instructions on exec-mask bookkeeping)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                int k = lane + 64 * r;
-                v[r] = k < K ? base[k] : fill;
+                const int k = lane + 64 * r;
+                if (r + 1 < R) {
+                    v[r] = base[k];
+                } else {
+                    const T x = base[k < K ? k : 0];
+                    v[r] = k < K ? x : fill;
+                }
             }
         }
     }
@@ -54,11 +62,13 @@ struct Row {
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                int k = lane + 64 * r;
-                if (k < K) base[k] = v[r];
+                const int k = lane + 64 * r;
+                if (r + 1 < R || k < K) base[k] = v[r];
             }
         }
     }
+    // does slot r of this lane hold an element of the row?  (strided layout: only the last slot can be past K)
+    __device__ __forceinline__ static bool live(int lane, int r, int K) { return PACKED || r + 1 < R || lane + 64 * r < K; }
     // element index of slot r (for atomics on single elements)
     __device__ __forceinline__ static int kof(int lane, int r) { return PACKED ? lane * R + r : lane + 64 * r; }
     __device__ __forceinline__ void fill(T x) {

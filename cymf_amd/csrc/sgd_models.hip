@@ -299,7 +299,7 @@ __device__ __forceinline__ void gl_atomic_add_row(float *__restrict__ dst, const
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int k = RowT::kof(lane, r);
-        if (RowT::packed || k < K) atomicAdd(dst + k, a.v[r] - b.v[r]);
+        if (RowT::live(lane, r, K)) atomicAdd(dst + k, a.v[r] - b.v[r]);
     }
 }
 template <typename RowT, int R>
@@ -307,7 +307,7 @@ __device__ __forceinline__ void gl_exchange_row(float *__restrict__ dst, RowT &c
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int k = RowT::kof(lane, r);
-        if (RowT::packed || k < K) {
+        if (RowT::live(lane, r, K)) {
             const float dlt = cur.v[r] - base.v[r];
             const float found = atomicAdd(dst + k, dlt);
             cur.v[r] = found + dlt;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void glove_step_kernel(GloveStepDev d, const i
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int k = RowT::kof(lane, r);
-                        if (k < K) {   // lanes past K hold zeros (also in the accumulators): keep 0/sqrt(0) out of w
+                        if (RowT::live(lane, r, K)) {   // lanes past K hold zeros (also in the accumulators): keep 0/sqrt(0) out of w
                             pbw += __frsqrt_rn(bw.y + (float)(k + 1) * g2);     // v_rsq_f32: the step kernel is VALU-heavy (4 roots and
                             pbh += __frsqrt_rn(bhq[e].y + (float)(k + 1) * g2); // 4 divisions per element and pair with sqrt + div)
                             const float wv = w.v[r], hv = hq[e].v[r];
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void relmf_step_kernel(RelStepDev d, const int
                             const float gw = -(cc * hv) + d.wd * wv;
                             const float gh = -(cc * wv) + d.wd * hv;
                             float dummy = 0;
-                            if (RowT::packed || RowT::kof(lane, r) < K) {   // masked lanes hold zeros: keep 0/sqrt(0) out
+                            if (RowT::live(lane, r, K)) {   // masked lanes hold zeros: keep 0/sqrt(0) out
                                 opt_update<float, OPT, true>(d.opt, w.v[r], OPT >= 1 ? sw[0].v[r] : dummy, OPT == 2 ? sw[NSA - 1].v[r] : dummy, gw);
                                 opt_update<float, OPT, true>(d.opt, hq[e].v[r], OPT >= 1 ? shq[e][0].v[r] : dummy,
                                                              OPT == 2 ? shq[e][NSA - 1].v[r] : dummy, gh);
