@@ -312,12 +312,13 @@ MFMA_F32_PEAK = 157.3e12   # FLOP/s, MI355X_MICROARCH.md chip table (fp32 matrix
 
 
 def _timed_epochs(run, n, device):
-    """ms per call of run() (one epoch), device-synchronised wall time over n calls after one warm-up call."""
-    run()
+    """ms per epoch: device-synchronised wall time of ONE call run(n) (n epochs back to back, as fit() runs them) after a
+    warm-up call run(1) -- n separate calls would put a host round trip (loss read-back) between the epochs, which on a
+    busy host moved the GloVe figure between 18 and 22 ms."""
+    run(1)
     _lib.device_sync(device)
     t0 = time.perf_counter()
-    for _ in range(n):
-        run()
+    run(n)
     _lib.device_sync(device)
     return 1e3 * (time.perf_counter() - t0) / n
 
@@ -365,7 +366,7 @@ def secondary_paths(device, scale=1.0):
         t.set_profiling(True)
         t.kernel_time()
         n = 50
-        ms = _timed_epochs(lambda: t.steps(1), n, device)
+        ms = _timed_epochs(lambda k: t.steps(k), n, device)
         p1, _ = t.stats()
         k_ms, k_n, _ = t.kernel_time()
         t.close()
@@ -389,7 +390,7 @@ def secondary_paths(device, scale=1.0):
             t = WmfTrainer(U, I, Kx, 10.0, 0.01, dtype="float32", device=device)
             t.set_data(X.indptr, X.indices, Xt.indptr, Xt.indices)
             t.upload(W, H)
-            ms = _timed_epochs(lambda: t.epochs(1), 5, device)
+            ms = _timed_epochs(lambda k: t.epochs(k), 5, device)
             t.close()
             # 2 (2 K^2 nnz) Gramian + (U+I)(2/3 K^3 + 2 K^2) solve + 2 (U+I) K^2 YtY
             flops = 2 * (2 * Kx * Kx * X.nnz) + (U + I) * (2.0 / 3.0 * Kx ** 3 + 2 * Kx * Kx) + 2 * (U + I) * Kx * Kx
@@ -418,7 +419,7 @@ def secondary_paths(device, scale=1.0):
         t = GloveTrainer(V, V, K, 0.05, 10.0, 0.75, dtype="float32", mode="throughput", device=device)
         t.set_data(ce, cx, cnt)
         t.upload(W, b, Wc, bc)
-        ms = _timed_epochs(lambda: t.epochs(1), 5, device)
+        ms = _timed_epochs(lambda k: t.epochs(k), 5, device)
         t.close()
         return {"workload": f"C5: V={V}, {len(ce)} pairs, K={K}, AdaGrad lr 0.05, lock-free mode", "value": len(ce) / (ms * 1e-3),
                 "unit": "pairs/s", "ms": ms, "roofline": _hbm_roofline(len(ce), 32 * K + 44, ms, "glove_step_kernel")}
@@ -433,7 +434,7 @@ def secondary_paths(device, scale=1.0):
         t = RelMfTrainer(U, I, K, "sgd", 0.01, 0.01, 0.1, mode="throughput", device=device)
         t.set_data(X, prop)
         t.upload(W, H)
-        ms = _timed_epochs(lambda: t.epochs(1), 4, device)
+        ms = _timed_epochs(lambda k: t.epochs(k), 4, device)
         t.close()
         return {"workload": f"RelMF {U} x {I} dense, K={K}, sgd, {U*I} draws per epoch, lock-free mode", "value": U * I / (ms * 1e-3),
                 "unit": "draws/s", "ms": ms, "roofline": _hbm_roofline(U * I, 16 * K + 8, ms, "relmf step kernels")}
