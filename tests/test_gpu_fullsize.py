@@ -187,8 +187,11 @@ def test_c3_eight_virtual_ranks_track_the_single_rank():
     assert abs(r1 - r8) < 0.03 and r8 > 0.15
 
 
-def test_c4_wmf_full_size_normal_equations():
-    U, I, nnz, K, seed = synthetic.CONFIGS["C4"]
+@pytest.mark.parametrize("K", [64, 128])
+def test_c4_wmf_full_size_normal_equations(K):
+    """K = 64: the register Gauss-Jordan row kernel (BASELINE config 4); K = 128: the blocked Cholesky with tiles parked in LDS.
+    Both with the longest-first work list, the long rows from segments on the side stream."""
+    U, I, nnz, _, seed = synthetic.CONFIGS["C4"]
     rows, cols, indptr = synthetic.implicit_matrix_large(U, I, nnz, seed)
     from scipy import sparse
     X = sparse.csr_matrix((np.ones(len(rows), dtype=np.float32), cols, indptr), shape=(U, I))
