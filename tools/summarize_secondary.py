@@ -63,7 +63,9 @@ lines = [f"# rocprofv3, secondary paths (round {tag[1:]}; tools/profile_round.sh
          " (and --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE for WMF), each its own pass)", ""]
 lines += section("WMF C4, K=64 then K=128, 4 epochs each", "wmf", "python3 tools/bench_models.py wmf", mfma=True,
                  note="MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): the share of SIMD cycles in which the matrix pipe "
-                      "executes (v_mfma_f32_32x32x2_f32: 64 cycles each).")
+                      "executes (v_mfma_f32_32x32x2_f32: 64 cycles each).  The long rows' segments (wmf_seg_kernel) and the fill of their scratch "
+                      "run on a second stream beside the whole-row kernels of the item sweep: their durations overlap the row kernel's "
+                      "(a 7 ms fill is a fill that waited for CUs) and the column does not add up to the epoch.")
 lines += section("RelMF 20000 x 8000, K=64, tile schedule: SGD, AdaGrad, Adam, 4 epochs each", "relmf", "python3 tools/relmf_check.py speed")
 for pre in ("wmf", "relmf"):
     log = os.path.join(root, pre + "_stats.log")
