@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(WMF_THREADS, 2) void wmf_seg_kernel(const int32_t *
 template <int T32, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_long_reg_kernel(const int32_t *__restrict__ long_rows,
                                                                               float *__restrict__ X, const float *__restrict__ A0,
-                                                                              const float *__restrict__ scratch, float weight) {
+                                                                              float *scratch, float weight) {
     constexpr int K = 32 * T32;
     using f4 = __attribute__((ext_vector_type(4))) float;
     extern __shared__ unsigned char smem_raw[];
@@ -1247,9 +1247,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_long_reg_kernel(
     asm volatile("" : "+v"(j));
     const int jr = j < K ? j : 0;
     const int32_t i = long_rows[blockIdx.x];
-    const float *G = scratch + (size_t)blockIdx.x * (K * K + K);
+    float *G = scratch + (size_t)blockIdx.x * (K * K + K);
     const f4 *a0 = reinterpret_cast<const f4 *>(A0 + (size_t)jr * K);
-    const f4 *g4 = reinterpret_cast<const f4 *>(G + (size_t)jr * K);
+    f4 *g4 = reinterpret_cast<f4 *>(G + (size_t)jr * K);
     f32x2 a[K / 2];
 #pragma unroll
     for (int g = 0; g < K / 4; ++g) {
@@ -1257,7 +1257,15 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_long_reg_kernel(
         a[2 * g] = f32x2{v[0], v[1]};
         a[2 * g + 1] = f32x2{v[2], v[3]};
     }
-    const float x = solve_reg<K, NW>(a, weight * G[K * K + jr], j, colbuf, bbuf);
+    const float bj = weight * G[K * K + jr];
+    // the slot is left zeroed for the next half-sweep's segments: no fill has to run (and be waited for) in front of them
+    // (lanes past K read row 0 again and may see these zeros: their values are never used)
+    if (j < K) {
+#pragma unroll
+        for (int g = 0; g < K / 4; ++g) g4[g] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        G[K * K + j] = 0.0f;
+    }
+    const float x = solve_reg<K, NW>(a, bj, j, colbuf, bbuf);
     if (j < K) X[(int64_t)i * K + j] = x;
 }
 
@@ -1331,6 +1339,7 @@ struct cymf_wmf {
     int32_t n_order[2] = {0, 0};
     int32_t n_segs[2] = {0, 0}, n_long[2] = {0, 0};
     DevBuf<float> d_scratch;
+    bool scratch_dirty = false;     // the last finish kernel did not leave its slots zeroed (the in-LDS finish)
     // YtY on the MFMA path: identity index list and segments over the rows of each table (0 = W, 1 = H)
     DevBuf<int32_t> d_iota;
     DevBuf<cymf::WmfSeg> d_gram_segs[2];
@@ -1427,7 +1436,12 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
                 CYMF_HIP(hipEventRecord(h->ev_ready, h->stream));   // YtY + lambda I is complete, the previous sweep's table too
                 CYMF_HIP(hipStreamWaitEvent(ss, h->ev_ready, 0));
             }
-            if (nlong > 0) CYMF_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)nlong * ((size_t)K * K + K) * sizeof(float), ss));
+            // (the register finish kernel leaves its slots zeroed; the in-LDS finish does not)
+            if (nlong > 0 && (!reg_ok || h->scratch_dirty)) {
+                CYMF_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)nlong * ((size_t)K * K + K) * sizeof(float), ss));
+                h->scratch_dirty = false;
+            }
+            if (nlong > 0 && !reg_ok) h->scratch_dirty = true;
             const int grid_seg = (int)std::min<int64_t>(nseg, 256 * 16);
             const bool sorted = h->row_order && h->d_order[side].p;
             const int32_t *order = sorted ? h->d_order[side].p : nullptr;
@@ -1656,6 +1670,7 @@ extern "C" int cymf_wmf_set_data(cymf_wmf *h, const int32_t *indptr, const int32
         max_long = std::max(max_long, longs.size());
     }
     CYMF_TRY(h->d_scratch.alloc(std::max<size_t>(1, max_long * ((size_t)h->K * h->K + h->K))));
+    CYMF_TRY(h->d_scratch.zero(h->stream));
     CYMF_TRY(h->d_ticks.alloc(8));
     CYMF_TRY(h->d_ticks.zero(h->stream));
     {
