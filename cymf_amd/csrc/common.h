@@ -133,17 +133,20 @@ __device__ __forceinline__ float dpp_f32(float v) {
 }
 
 // Sum over the 64 lanes, result in every lane (wave-uniform value, usable as SGPR).
-// 4 DPP steps inside each row of 16, then the 4 row sums are read with v_readlane.
+// 4 DPP steps inside each row of 16 (every lane then holds its row's sum), then row_bcast:15 adds row 0 into row 1 and row 2
+// into row 3, row_bcast:31 adds (row 0 + row 1) into rows 2 and 3: lane 63 holds (r3 + r2) + (r1 + r0) -- the same two pair
+// sums and the same final addition as reading the four row sums with v_readlane and adding them, bit for bit, in three
+// instructions instead of eight.  Inline assembly: written with update_dpp the compiler emits a v_mov_b32_dpp and a
+// separate add per step; the s_nop are the two wait states a DPP read needs after the VALU write of its operand.
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<DPP_QUAD_PERM_1032>(v);
     v += dpp_f32<DPP_QUAD_PERM_2301>(v);
     v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);
     v += dpp_f32<DPP_ROW_MIRROR>(v);
-    float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return (a + b) + (c + d);
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
