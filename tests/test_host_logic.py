@@ -335,3 +335,20 @@ def test_jump_polynomial_header_matches_its_generator():
         have = sum(w << (32 * i) for i, w in enumerate(words[lvl * 624:(lvl + 1) * 624]))
         assert have == g, lvl
         g = gen.gf2_mod(gen.gf2_square(gen.gf2_mod(gen.gf2_square(g), phi)), phi)
+
+
+def test_micro_benchmarks_cross_compile(tmp_path):
+    """tools/micro/*.hip are the standalone programs behind profiles/r02_lds_atomics.md, r02_permlane_hazard.md and the
+    bit-identity claim of wave_sum: they must keep building for gfx950 (hipcc cross-compiles without a GPU)."""
+    import glob
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    srcs = sorted(glob.glob(os.path.join(ROOT, "tools", "micro", "*.hip")))
+    assert srcs
+    for src in srcs:
+        out = str(tmp_path / (os.path.basename(src) + ".o"))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", out],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
