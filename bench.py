@@ -2,7 +2,10 @@
 """bench.py -- BPR triplet-updates/sec at K=128 on MI355X (BASELINE.json metric), HBM roofline beside it.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT are read from the environment) or started plainly, as above: this
+    process then stays a launcher -- it starts the N ranks as fresh child processes before anything here has touched
+    HIP or RCCL, passes rank 0's JSON line through, and exits non-zero (after ending the other ranks) if any rank does.
 
 Workload (config C3): synthetic 1M users x 100k items, 100M interactions
 (lognormal user activity, Zipf(1) item popularity, seed 102), K=128, SGD lr=0.05 wd=0.01, fp32,
@@ -36,7 +39,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from cymf_amd import _lib, dist, synthetic  # noqa: E402
+from cymf_amd import _lib, dist, synthetic  # noqa: E402   (pure Python: libcymf_hip.so is only loaded by the first _lib.lib() call)
 from cymf_amd.bpr import BprTrainer  # noqa: E402
 
 HBM_PEAK = 8.0e12   # B/s, MI355X_MICROARCH.md chip table
@@ -98,6 +101,52 @@ def shared_dataset(rank, local, world, config, scale):
     return U, I, K, {n: np.load(os.path.join(d, n + ".npy"), mmap_mode="r") for n in names}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: be the launcher.  Nothing in this process has loaded libcymf_hip or
+    called HIP (a process that has must never be replaced or forked into ranks); the N ranks are fresh interpreters
+    running this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, as torch.distributed.run would set them.  Rank 0
+    inherits stdout (its one JSON line is the launcher's), the other ranks' stdout goes to stderr.  The first rank that
+    fails ends the run: the others are killed by pid and the launcher returns that rank's code."""
+    import shutil
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               TORCHELASTIC_RUN_ID=f"bench{os.getpid()}", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive and rc == 0:
+            time.sleep(0.2)
+            for p in list(alive):
+                code = p.poll()
+                if code is not None:
+                    alive.remove(p)
+                    if code != 0:
+                        rc = code if code > 0 else 128 - code
+                        print(f"[bench] rank {procs.index(p)} exited with {code}: ending the other ranks", file=sys.stderr, flush=True)
+                        break
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        for d in os.listdir("/dev/shm") if os.path.isdir("/dev/shm") else []:    # the node's dataset, if a rank died holding it
+            if d.startswith(f"cymf_bench_{port}_{os.getpid()}_"):
+                shutil.rmtree(os.path.join("/dev/shm", d), ignore_errors=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,10 +163,13 @@ def main():
                          "compute cost of the sharded schedule without the exchange; the line is marked and is not a result")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        assert _lib._lib is None, "the launcher must not have loaded libcymf_hip"
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank, world, local = dist.env_rank_world()
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = local if os.environ.get("CYMF_BENCH_SAME_DEVICE") != "1" else 0   # (test hook: all ranks on device 0)
     lr, wd = 0.05, 0.01
 
@@ -212,7 +264,7 @@ def main():
             traffic = None
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and not pretend:
         import oracle   # the CPU baseline leg: the oracle is the thing timed here, never the product path
         n = min(args.cpu_sample, nnz)
         ip32, u32, p32 = indptr.astype(np.int32), users[:n].copy(), positives[:n].copy()
@@ -243,7 +295,7 @@ def main():
                          f"sequential 1-thread port: {rate1:.0f} triplet-updates/s ({dt1:.1f}s); host: {cpu_model}, omp_get_max_threads()={oracle.max_threads()}"}
 
     copy_gbps = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not pretend:
         try:
             copy_gbps = _lib.stream_copy_gbps(device, 1 << 30, 10)
         except Exception:
@@ -252,7 +304,7 @@ def main():
     trainer.close()
     del trainer
     secondary = None
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary and not pretend:
         del data, users, positives, W0, H0
         secondary = secondary_paths(device, args.scale)
 
@@ -261,7 +313,6 @@ def main():
                           "steps": args.steps, "steps_per_epoch": spe, "ms_per_step": elapsed / args.steps * 1e3,
                           "local_triplets_per_step": performed_local / args.steps, "kernel_ms_per_step": k_ms / max(k_launches, 1),
                           "job_rate_if_exchange_hidden": performed_local * pretend / elapsed}))
-        trainer.close()
         comm.close()
         return
     if rank == 0:
@@ -274,9 +325,10 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
-            "scaling_note": "fixed data set (C3) sharded by user: the per-GPU step stays at ~4-6 M triplets, the global step grows "
-                            "with N and the steps per epoch shrink as 1/N (synchronous mini-batch on the item table, SURVEY.md 8e)",
+            "scaling": "strong",
+            "scaling_note": "fixed data set (C3: an epoch is the same 100 M triplets at every N) sharded by user; the per-GPU step stays "
+                            "at ~4-6 M triplets, so the global step grows with N, the steps per epoch shrink as 1/N and the K timed "
+                            "steps cover N times as many epochs (`epochs_covered`); synchronous mini-batch on the item table, SURVEY.md 8e",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",

@@ -14,73 +14,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class _FakeFn:
-    def __init__(self, fn):
-        self.fn = fn
-
-    def __call__(self, *a):
-        return self.fn(*a)
-
-
-class FakeCommLib:
-    """cymf_comm_unique_id / create / destroy / allreduce_f32 over files in a scratch directory: rank 0's id is a random
-    token; create() fails if the id a rank presents is not the token rank 0 published; allreduce meets in the directory."""
-
-    def __init__(self, scratch):
-        self.scratch = scratch
-        self.handles = {}
-        self.calls = []
-        self.cymf_comm_unique_id = _FakeFn(self._unique_id)
-        self.cymf_comm_create = _FakeFn(self._create)
-        self.cymf_comm_destroy = _FakeFn(self._destroy)
-        self.cymf_comm_allreduce_f32 = _FakeFn(self._allreduce)
-        self.cymf_last_error = _FakeFn(lambda: b"fake error")
-
-    def _unique_id(self, buf):
-        token = os.urandom(128)
-        C.memmove(buf, token, 128)
-        with open(os.path.join(self.scratch, "token"), "wb") as f:
-            f.write(token)
-        return 0
-
-    def _create(self, out_ref, id_buf, rank, world, device):
-        want = open(os.path.join(self.scratch, "token"), "rb").read()
-        if bytes(id_buf.raw[:128]) != want:
-            return -4
-        h = 1000 + rank
-        self.handles[h] = (rank, world, 0)
-        out_ref._obj.value = h
-        self.calls.append(("create", rank, world, device))
-        return 0
-
-    def _destroy(self, h):
-        self.calls.append(("destroy", h.value if hasattr(h, "value") else h))
-        return 0
-
-    def _allreduce(self, h, ptr, n, op):
-        rank, world, gen = self.handles[h.value]
-        self.handles[h.value] = (rank, world, gen + 1)
-        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n,))
-        np.save(os.path.join(self.scratch, f"ar{gen}_{rank}.npy.tmp"), a)
-        os.replace(os.path.join(self.scratch, f"ar{gen}_{rank}.npy.tmp.npy"), os.path.join(self.scratch, f"ar{gen}_{rank}.npy"))
-        t0 = time.time()
-        parts = []
-        for r in range(world):
-            p = os.path.join(self.scratch, f"ar{gen}_{r}.npy")
-            while not os.path.exists(p):
-                if time.time() - t0 > 20:
-                    return -4
-                time.sleep(0.01)
-            parts.append(np.load(p))
-        a[:] = np.max(parts, axis=0) if op == 1 else np.sum(parts, axis=0)
-        return 0
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fakelib import FakeCommLib  # noqa: E402
 
 
 def _rank_main(rank, world, port, scratch, mode, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_PORT=str(port),
                       MASTER_ADDR="127.0.0.1", TORCHELASTIC_RUN_ID="t")
     from cymf_amd import _lib, dist
+    from fakelib import FakeCommLib
     fake = FakeCommLib(scratch)
     _lib.lib = lambda: fake            # the product code asks _lib.lib() for the library on every call
     try:
