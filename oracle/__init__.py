@@ -21,18 +21,43 @@ _lib = None
 OPT_IDS = {"sgd": 0, "adagrad": 1, "adam": 2}
 
 
+# the CPU baseline is built `-O3 -fopenmp -ffp-contract=off` (no FMA contraction: the reference's
+# x86-64 build has none)
+CFLAGS = ["-O3", "-ffp-contract=off", "-fopenmp", "-std=c99", "-fPIC", "-shared", "-Wall"]
+# SURVEY.md section 5 (race detection / sanitizers): the same source under AddressSanitizer + UBSan, for tests only
+SAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+             "-ffp-contract=off", "-fopenmp", "-std=c99", "-fPIC", "-shared", "-Wall"]
+_SAN_SO = os.path.join(_HERE, "libcymf_oracle_san.so")
+
+
+def _build_one(so, flags, force):
+    stamp = so + ".flags"
+    want = " ".join(flags)
+    have = open(stamp).read() if os.path.exists(stamp) else None
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(_SRC) or have != want:
+        subprocess.check_call(["gcc"] + flags + [_SRC, "-o", so, "-lm"])
+        with open(stamp, "w") as f:
+            f.write(want)
+    return so
+
+
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-std=c99", "-fPIC", "-shared",
-                               "-Wall", _SRC, "-o", _SO, "-lm"])
-    return _SO
+    return _build_one(_SO, CFLAGS, force)
+
+
+def build_sanitized(force: bool = False) -> str:
+    """libcymf_oracle_san.so: cymf_oracle.c under -fsanitize=address,undefined.  Load it in a process started with
+    LD_PRELOAD=<libasan> and CYMF_ORACLE_SO pointing at it (tests/test_oracle_sanitized.py)."""
+    return _build_one(_SAN_SO, SAN_FLAGS, force)
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+        so = os.environ.get("CYMF_ORACLE_SO")      # the sanitizer build, tests only
+        if not so:
+            so = build()
+        L = C.CDLL(so)
         vp, i32, i64, u32, u64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
         L.orc_rng_fill_uniform.argtypes = [u32, u64, i64, i64, vp]
         L.orc_rng_fill_uniform.restype = None
