@@ -797,7 +797,7 @@ struct cymf_bpr {
 
 namespace cymf {
 int comm_allreduce_sum_f32(cymf_comm *c, float *d_buf, int64_t n, hipStream_t s);   // comm.hip
-int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, hipStream_t s);
+int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, int64_t cap, hipStream_t s);
 int64_t comm_padded_count(cymf_comm *c, int64_t n);
 int comm_allgatherv(cymf_comm *c, void *d_buf, const int64_t *row_bounds, int64_t row_bytes, hipStream_t s);
 int comm_rank(cymf_comm *c);
@@ -1270,7 +1270,7 @@ int run_one_step(cymf_bpr *h) {
         CYMF_TRY(finish_exchange(h, /*snapshot_if_idle=*/true, h->d_local[b].p));
         CYMF_HIP(hipEventRecord(h->ev_delta_ready, h->stream));
         CYMF_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_delta_ready, 0));
-        CYMF_TRY(comm_allreduce_sum_f32_to(h->comm, h->d_local[b].p, h->d_glob[b].p, n, h->comm_stream));
+        CYMF_TRY(comm_allreduce_sum_f32_to(h->comm, h->d_local[b].p, h->d_glob[b].p, n, (int64_t)std::min(h->d_local[b].n, h->d_glob[b].n), h->comm_stream));
         CYMF_HIP(hipEventRecord(h->ev_reduced[b], h->comm_stream));
         h->exch_pending = true;
         h->exch_parity = b;
@@ -1587,7 +1587,7 @@ extern "C" int cymf_bpr_upload(cymf_bpr *h, const double *W, const double *H) {
         if (h->comm_stream) CYMF_HIP(hipStreamSynchronize(h->comm_stream));   // (a re-upload drops an exchange in flight)
         CYMF_TRY(h->d_snap.alloc(n));
         if (h->overlap_exchange) {
-            // the exchange is a reduce-scatter + all-gather over equal shards: buffers padded to a multiple of the world, padding zero
+            // padded to a multiple of the world, padding zero: what the reduce-scatter + all-gather form of the exchange (CYMF_COMM_RS_AG=1) needs
             const size_t n_pad = (size_t)comm_padded_count(h->comm, (int64_t)n);
             for (int b = 0; b < 2; ++b) {
                 CYMF_TRY(h->d_local[b].alloc(n_pad)); CYMF_TRY(h->d_glob[b].alloc(n_pad));

@@ -117,6 +117,34 @@ int local_allreduce(cymf_comm *c, const float *d_in, float *d_out, int64_t n, in
         [&](const float *slots) { hipLaunchKernelGGL(local_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, s, slots, c->grp->cap, c->world, d_out, n, op); });
 }
 
+// The padded reduce-scatter + all-gather layout on the local group (n % world != 0 included), so that the offsets and the
+// padding rule of the CYMF_COMM_RS_AG path run on the one-GPU box: every rank publishes its padded input and reduces the
+// ranks' copies of ITS shard of padded / world floats into place in d_out; the ranks meet again, publish their shards and
+// copy the others' into place.  Two meetings, as the two RCCL calls are two collectives; equal to local_allreduce bit for
+// bit (the same rank order of the additions).
+int local_rs_ag(cymf_comm *c, const float *d_in, float *d_out, int64_t n, int64_t cap, hipStream_t s) {
+    const int64_t w = c->world, padded = (n + w - 1) / w * w, shard = padded / w;
+    if (padded > cap) return fail(CYMF_ERR_INVALID, "local group: reduce-scatter + all-gather of %lld floats over %d ranks needs buffers of %lld, have %lld",
+                                  (long long)n, c->world, (long long)padded, (long long)cap);
+    if ((size_t)padded > c->grp->cap) return fail(CYMF_ERR_INVALID, "local group: %lld floats exceed the slot size %zu", (long long)padded, c->grp->cap);
+    float *my_shard = d_out + (size_t)c->rank * shard;
+    // reduce-scatter: publish the padded input; reduce the ranks' copies of MY shard
+    CYMF_TRY(local_collective(c, (size_t)padded, s,
+        [&](float *slot) { hipLaunchKernelGGL(local_publish_kernel, dim3(blocks_for(padded)), dim3(256), 0, s, d_in, slot, padded); },
+        [&](const float *slots) {
+            hipLaunchKernelGGL(local_reduce_kernel, dim3(blocks_for(shard)), dim3(256), 0, s, slots + (size_t)c->rank * shard, c->grp->cap, c->world, my_shard, shard, 0);
+        }));
+    // all-gather: publish my reduced shard; copy every rank's shard into place
+    return local_collective(c, (size_t)shard, s,
+        [&](float *slot) { hipLaunchKernelGGL(local_publish_kernel, dim3(blocks_for(shard)), dim3(256), 0, s, my_shard, slot, shard); },
+        [&](const float *slots) {
+            for (int r = 0; r < c->world; ++r) {
+                if (r == c->rank) continue;
+                hipLaunchKernelGGL(local_publish_kernel, dim3(blocks_for(shard)), dim3(256), 0, s, slots + (size_t)r * c->grp->cap, d_out + (size_t)r * shard, shard);
+            }
+        });
+}
+
 }  // namespace
 }  // namespace cymf
 
@@ -149,15 +177,35 @@ int64_t comm_padded_count(cymf_comm *c, int64_t n) {
     return (n + w - 1) / w * w;
 }
 
-// d_out = sum over the ranks of d_in, as reduce-scatter + all-gather: each rank reduces one shard of
-// 1 / world of the table and the shards are gathered in place -- the two halves of a ring all-reduce, issued as such so
-// that the per-link traffic over xGMI is (world - 1) / world of the table each way and a shard is reduced once.  Two
-// calls in stream order (not one group: the all-gather reads what the reduce-scatter wrote, and a group promises no
-// order between its members).  Both buffers hold comm_padded_count(n) floats.
-int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, hipStream_t s) {
-    if (c->grp) return local_allreduce(c, d_in, d_out, n, 0, s);
+// d_out = sum over the ranks of d_in (out of place; `cap` = floats BOTH buffers hold).
+//  * default: one ncclAllReduce.  RCCL's ring all-reduce already is a reduce-scatter followed by an all-gather, and no
+//    run with more than one rank has been measured yet (the development box has one GPU), so the library's own choice of
+//    algorithm stands until a measurement says otherwise.
+//  * CYMF_COMM_RS_AG=1: the two halves issued explicitly on padded equal shards (per link (world - 1) / world
+//    of the table each way, every shard reduced once).  Two calls in stream order (not one group: the all-gather reads what
+//    the reduce-scatter wrote, and a group promises no order between its members).  Needs cap >= comm_padded_count(n) and the
+//    padding of d_in zero (the callers allocate and zero both at upload); checked here.
+static bool comm_rs_ag() {   // (read on every call: the tests switch it inside one process)
+    const char *e = getenv("CYMF_COMM_RS_AG");
+    return e && e[0] == '1';
+}
+
+int comm_allreduce_sum_f32_to(cymf_comm *c, const float *d_in, float *d_out, int64_t n, int64_t cap, hipStream_t s) {
+    if (n > cap) return fail(CYMF_ERR_INVALID, "comm_allreduce_sum_f32_to: %lld floats into buffers of %lld", (long long)n, (long long)cap);
+    if (c->grp) {
+        if (comm_rs_ag()) return local_rs_ag(c, d_in, d_out, n, cap, s);
+        return local_allreduce(c, d_in, d_out, n, 0, s);
+    }
     if (c->failed) return fail(CYMF_ERR_RCCL, "communicator of rank %d is in a failed state", c->rank);
-    const int64_t shard = comm_padded_count(c, n) / c->world;
+    if (!comm_rs_ag()) {
+        CYMF_NCCL_C(c, ncclAllReduce(d_in, d_out, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
+        return comm_check_async(c, "ncclAllReduce");
+    }
+    const int64_t padded = comm_padded_count(c, n);
+    if (padded > cap)
+        return fail(CYMF_ERR_INVALID, "comm_allreduce_sum_f32_to: reduce-scatter + all-gather of %lld floats over %d ranks needs buffers of %lld, have %lld",
+                    (long long)n, c->world, (long long)padded, (long long)cap);
+    const int64_t shard = padded / c->world;
     CYMF_NCCL_C(c, ncclReduceScatter(d_in, d_out + (size_t)c->rank * shard, (size_t)shard, ncclFloat32, ncclSum, c->comm, s));
     CYMF_NCCL_C(c, ncclAllGather(d_out + (size_t)c->rank * shard, d_out, (size_t)shard, ncclFloat32, c->comm, s));
     return comm_check_async(c, "reduce-scatter + all-gather");
@@ -277,23 +325,30 @@ extern "C" int cymf_comm_destroy(cymf_comm *c) {
 extern "C" int cymf_comm_allreduce_f32(cymf_comm *c, float *host_inout, int64_t n, int op) {
     if (!c || !host_inout || n < 0) return fail(CYMF_ERR_INVALID, "cymf_comm_allreduce_f32: bad arguments");
     CYMF_TRY(use_device(c->device));
-    DevBuf<float> d;
-    CYMF_TRY(d.upload(host_inout, (size_t)n));
-    if (c->grp) {   // (no device-wide synchronisation here: another rank's thread may be blocked inside a collective)
-        hipStream_t s = nullptr;
-        CYMF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        DevBuf<float> dl;
-        int rc = dl.upload(host_inout, (size_t)n, s);
-        if (!rc) rc = local_allreduce(c, dl.p, dl.p, n, op == 1 ? 1 : 0, s);
-        if (!rc && hipMemcpyAsync(host_inout, dl.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(CYMF_ERR_HIP, "copy failed");
-        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(CYMF_ERR_HIP, "sync failed");
-        (void)hipStreamDestroy(s);
-        return rc;
+    // (no device-wide synchronisation on the local group: another rank's thread may be blocked inside a collective)
+    hipStream_t s = nullptr;
+    CYMF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const bool rs_ag = op != 1 && comm_rs_ag();       // sums take the same route as the trainers' exchange (tests)
+    const size_t cap = rs_ag ? (size_t)comm_padded_count(c, n) : (size_t)n;
+    DevBuf<float> din, dout;
+    int rc = din.alloc(std::max<size_t>(cap, 1));
+    if (!rc) rc = dout.alloc(std::max<size_t>(cap, 1));
+    if (!rc) rc = din.zero(s);                        // the padding of the reduce-scatter input must be zero
+    if (!rc && n > 0 && hipMemcpyAsync(din.p, host_inout, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) rc = fail(CYMF_ERR_HIP, "copy failed");
+    if (!rc && !c->grp && hipStreamSynchronize(s) != hipSuccess) rc = fail(CYMF_ERR_HIP, "sync failed");
+    if (!rc) {
+        if (rs_ag) rc = comm_allreduce_sum_f32_to(c, din.p, dout.p, n, (int64_t)cap, s);
+        else if (c->grp) rc = local_allreduce(c, din.p, dout.p, n, op == 1 ? 1 : 0, s);
+        else if (c->failed) rc = fail(CYMF_ERR_RCCL, "communicator of rank %d is in a failed state", c->rank);
+        else {
+            ncclResult_t r = ncclAllReduce(din.p, dout.p, (size_t)n, ncclFloat32, op == 1 ? ncclMax : ncclSum, c->comm, s);
+            if (r != ncclSuccess) { c->failed = true; rc = fail(CYMF_ERR_RCCL, "ncclAllReduce failed on rank %d of %d: %s", c->rank, c->world, ncclGetErrorString(r)); }
+            else rc = comm_check_async(c, "ncclAllReduce");
+        }
     }
-    if (c->failed) return fail(CYMF_ERR_RCCL, "communicator of rank %d is in a failed state", c->rank);
-    CYMF_HIP(hipDeviceSynchronize());
-    CYMF_NCCL_C(c, ncclAllReduce(d.p, d.p, (size_t)n, ncclFloat32, op == 1 ? ncclMax : ncclSum, c->comm, nullptr));
-    CYMF_TRY(comm_check_async(c, "ncclAllReduce"));
-    CYMF_HIP(hipMemcpy(host_inout, d.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    return 0;
+    if (!rc && n > 0 && hipMemcpyAsync(host_inout, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(CYMF_ERR_HIP, "copy failed");
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(CYMF_ERR_HIP, "sync failed");
+    (void)hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    return rc;
 }

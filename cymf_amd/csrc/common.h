@@ -138,12 +138,15 @@ __device__ __forceinline__ float dpp_f32(float v) {
 // sums and the same final addition as reading the four row sums with v_readlane and adding them, bit for bit, in three
 // instructions instead of eight.  Inline assembly: written with update_dpp the compiler emits a v_mov_b32_dpp and a
 // separate add per step; the s_nop are the two wait states a DPP read needs after the VALU write of its operand.
+// `volatile`: a cross-lane instruction must execute with the EXEC mask of this point.  Several callers consume the sum only
+// under `if (lane == 0)`; hipcc has sunk a non-volatile cross-lane asm into such a masked branch before
+// (profiles/r02_permlane_hazard.md), where row_bcast would read lanes that are switched off.
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f32<DPP_QUAD_PERM_1032>(v);
     v += dpp_f32<DPP_QUAD_PERM_2301>(v);
     v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);
     v += dpp_f32<DPP_ROW_MIRROR>(v);
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
         "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
         : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

@@ -277,8 +277,9 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     __syncthreads();
     // draws per cell: item il of user ul is byte (il >> 4) of word [ul][il & 15] -- lane l of a worker reads ONE word
     // and holds the counts of items l, 16 + l, 32 + l, 48 + l (ib <= 64).  A byte cannot overflow in practice: a cell is
-    // drawn Poisson(1) times per epoch; 255 is clamped below all the same (the surplus draws of such a cell are dropped
-    // and reported through err).
+    // drawn Poisson(1) times per epoch.  If one did (old value 255), the add has already carried into the neighbouring
+    // item's counter: it is taken back (adds and subtractions commute, nothing reads the words before the barrier), the
+    // 256th draw of that cell is NOT applied, and the epoch is failed through err = 2 -- no silent loss of a draw.
     for (uint32_t t = t0 + tid; t < t1; t += nthreads) {
         const uint32_t c = sorted[t];
         const uint32_t u = c / I, i = c - u * I;
@@ -286,7 +287,10 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
         if (ul < (uint32_t)nu && il < (uint32_t)ni) {
             const uint32_t slot = il / LPD;              // item il: lane il % LPD of a worker, its slot-th counter
             const uint32_t old = atomicAdd(&s_cc[ul * 16 + (il % LPD) * WPL + (slot >> 2)], 1u << (8 * (slot & 3)));
-            if (((old >> (8 * (slot & 3))) & 255u) == 255u) atomicExch(err, 2);   // counter overflow: never with uniform draws
+            if (((old >> (8 * (slot & 3))) & 255u) == 255u) {   // counter overflow: never with uniform draws
+                atomicSub(&s_cc[ul * 16 + (il % LPD) * WPL + (slot >> 2)], 1u << (8 * (slot & 3)));
+                atomicExch(err, 2);
+            }
         } else {
             atomicExch(err, 1);   // a cell outside its tile: broken bucketing must not become a wild LDS access
         }

@@ -1126,6 +1126,7 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
     if (stepped) CYMF_HIP(hipMemcpyAsync(&err, h->d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     CYMF_HIP(hipMemcpyAsync(&loss, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
+    if (err == 2) return fail(CYMF_ERR_HIP, "relmf: a cell was drawn more than 255 times inside one tile of one epoch (that draw was not applied)");
     if (err) return fail(CYMF_ERR_HIP, "relmf: the per-epoch bucketing produced an index outside its block");
     if (loss_out) *loss_out = loss;
     return 0;

@@ -1436,12 +1436,21 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
                 CYMF_HIP(hipEventRecord(h->ev_ready, h->stream));   // YtY + lambda I is complete, the previous sweep's table too
                 CYMF_HIP(hipStreamWaitEvent(ss, h->ev_ready, 0));
             }
-            // (the register finish kernel leaves its slots zeroed; the in-LDS finish does not)
-            if (nlong > 0 && (!reg_ok || h->scratch_dirty)) {
+            // The register finish kernel leaves its slots zeroed; the in-LDS finish does not -- and neither does a half-sweep that
+            // launched segments and then returned early (an error between here and the finish launch): the scratch counts as dirty
+            // from the moment segments may be written until the register finish kernel is enqueued behind them.
+            if (nlong > 0 && (!reg_ok || h->scratch_dirty))
                 CYMF_HIP(hipMemsetAsync(h->d_scratch.p, 0, (size_t)nlong * ((size_t)K * K + K) * sizeof(float), ss));
-                h->scratch_dirty = false;
-            }
-            if (nlong > 0 && !reg_ok) h->scratch_dirty = true;
+            if (nlong > 0) h->scratch_dirty = true;
+            struct SegJoin {   // an early return must not leave the segment stream running beside the next call
+                cymf_wmf *h; hipStream_t ss; bool armed;
+                void join() {
+                    if (!armed) return;
+                    armed = false;
+                    if (hipEventRecord(h->ev_segs, ss) == hipSuccess) (void)hipStreamWaitEvent(h->stream, h->ev_segs, 0);
+                }
+                ~SegJoin() { join(); }
+            } seg_join{h, ss, ss != h->stream};
             const int grid_seg = (int)std::min<int64_t>(nseg, 256 * 16);
             const bool sorted = h->row_order && h->d_order[side].p;
             const int32_t *order = sorted ? h->d_order[side].p : nullptr;
@@ -1486,10 +1495,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             default: WMF_LAUNCH_(4); break;
             }
 #undef WMF_LAUNCH_
-            if (ss != h->stream) {
-                CYMF_HIP(hipEventRecord(h->ev_segs, ss));
-                CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_segs, 0));
-            }
+            seg_join.join();
             if (nlong > 0 && reg_ok) {
 #define WMF_FINISH_(T32_)                                                                                                   \
     do {                                                                                                                    \
@@ -1504,6 +1510,7 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
                 default: WMF_FINISH_(4); break;
                 }
 #undef WMF_FINISH_
+                h->scratch_dirty = false;   // enqueued: its slots are zero again when it has run
             } else if (nlong > 0) {
                 CYMF_TRY(allow_lds(wmf_long_finish_kernel, smem));
                 hipLaunchKernelGGL(wmf_long_finish_kernel, dim3(nlong), dim3(WMF_THREADS), smem, h->stream, K, h->d_long_rows[side].p, Xf_all, Gf,

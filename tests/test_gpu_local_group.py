@@ -48,6 +48,30 @@ def test_local_group_allreduce_and_barrier():
         c.close()
 
 
+@pytest.mark.parametrize("n", [1000, 1001, 1002, 7, 2])
+def test_padded_reduce_scatter_all_gather_layout_equals_the_all_reduce(n, monkeypatch):
+    """CYMF_COMM_RS_AG=1: the exchange as reduce-scatter + all-gather on shards padded to a multiple of the world
+    size, n % world != 0 included -- same bits as the plain all-reduce (same rank order of the additions); a slot too small
+    for the padded count is refused, not overrun."""
+    world = 3
+    comms = dist.Comm.local_group(world, 1002)
+    rs = np.random.RandomState(n)
+    data = [rs.randn(n).astype(np.float32) for _ in range(world)]
+
+    def fn(r):
+        return comms[r].allreduce(data[r])
+
+    monkeypatch.setenv("CYMF_COMM_RS_AG", "0")
+    plain = _run_ranks(world, fn)
+    monkeypatch.setenv("CYMF_COMM_RS_AG", "1")
+    padded = _run_ranks(world, fn)
+    want = (data[0] + data[1]) + data[2]
+    for r in range(world):
+        assert np.array_equal(plain[r], want) and np.array_equal(padded[r], want)
+    for c in comms:
+        c.close()
+
+
 @pytest.mark.parametrize("sync_exchange", ["0", "1"])
 @pytest.mark.parametrize("optimizer,lr", [("sgd", 0.05), ("adam", 0.005)])
 def test_bpr_three_ranks_on_one_gpu(optimizer, lr, sync_exchange, monkeypatch):
@@ -79,6 +103,27 @@ def test_bpr_three_ranks_on_one_gpu(optimizer, lr, sync_exchange, monkeypatch):
     np.testing.assert_allclose(job_loss[-1], one.losses[-1], rtol=0.05)
     assert job_loss[-1] < job_loss[0]
     assert abs(np.linalg.norm(res[0][1]) / np.linalg.norm(one.H) - 1) < 0.15
+    for c in comms:
+        c.close()
+
+
+def test_bpr_three_ranks_with_the_reduce_scatter_all_gather_exchange(monkeypatch):
+    """The overlapped exchange in its CYMF_COMM_RS_AG=1 form (I * K = 800 * 31 is not a multiple of 3): replicas identical,
+    the job trains."""
+    monkeypatch.setenv("CYMF_COMM_RS_AG", "1")
+    X = synthetic.implicit_matrix(3000, 800, 90000, 91)
+    K, world = 31, 3
+    comms = dist.Comm.local_group(world, 800 * K + 3000 * K + 8)
+    shards = dist.user_shards(X.indptr, world)
+
+    def fn(r):
+        m = BPR(K, 0.05, "sgd", 0.01)
+        m.fit(X, num_epochs=6, num_threads=0, verbose=False, comm=comms[r], shard=shards[r], steps_per_epoch=4)
+        return m.H, np.array(m.losses)
+
+    res = _run_ranks(world, fn)
+    assert all(np.array_equal(H, res[0][0]) for H, _ in res) and np.isfinite(res[0][0]).all()
+    assert all(l[-1] < l[0] for _, l in res)
     for c in comms:
         c.close()
 
