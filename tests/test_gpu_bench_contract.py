@@ -23,7 +23,7 @@ def test_bench_line_contract():
         assert key in d, key
     assert d["metric"] == "BPR triplet-updates/sec at K=128" and d["unit"] == "triplet-updates/s"
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["launches"] == 6
