@@ -84,6 +84,7 @@ def lib():
         "cymf_bpr_create": ([pp, i32, i32, i32, ci, f64, f64, u32, ci, ci, ci], ci),
         "cymf_bpr_set_data": ([vp, vp, vp, i64, vp, vp, vp, i64], ci),
         "cymf_bpr_set_steps_per_epoch": ([vp, i32], ci),
+        "cymf_bpr_get_steps_per_epoch": ([vp, vp], ci),
         "cymf_bpr_upload": ([vp, vp, vp], ci),
         "cymf_bpr_download": ([vp, vp, vp], ci),
         "cymf_bpr_epochs": ([vp, i32, vp], ci),

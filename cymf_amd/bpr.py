@@ -28,13 +28,15 @@ class BPR(object):
             raise Exception(f"{self.optimizer} is invalid.")   # cymf/bpr.pyx:65-66
 
     def fit(self, X, num_epochs=10, num_threads=1, valid_evaluator=None, early_stopping=False, verbose=True,
-            *, mode=None, dtype=None, device=0, steps_per_epoch=1, comm=None, shard=None):
+            *, mode=None, dtype=None, device=0, steps_per_epoch=None, comm=None, shard=None):
         """Train in place.  Positional arguments as cymf/bpr.pyx:68.
 
         num_threads == 1 (the reference's deterministic setting) selects the exact sequential-order
         mode, any other value its HOGWILD counterpart (throughput mode); `mode=` overrides.
         Keyword-only extras: dtype ('float32' | 'float64' device arithmetic), device, and for
-        throughput mode steps_per_epoch / comm / shard (see cymf_amd.dist).
+        throughput mode steps_per_epoch / comm / shard (see cymf_amd.dist).  steps_per_epoch = windows of the shuffled order
+        inside which the triplets are bucketed by positive item; None = chosen from the data so that the lock-free mode follows
+        the reference's order closely; the number used is left in `steps_per_epoch_`.
         """
         X = _host.coerce_csr(X)
         self.valid_evaluator = valid_evaluator
@@ -68,6 +70,7 @@ class BPR(object):
                 if tuple(all_shards[comm.rank]) == tuple(shard):
                     trainer.set_user_bounds([lo for lo, _ in all_shards] + [all_shards[-1][1]])
             trainer.set_data(users, positives, indptr, indices, global_pos, n_global)
+            self.steps_per_epoch_ = trainer.steps_per_epoch()
             trainer.upload(self.W, self.H)
             stopper = _host.EarlyStopping(self)
             bar = _host.Progress(num_epochs, verbose)
@@ -103,10 +106,15 @@ class BprTrainer:
                                           neg_seed, _lib.DTYPE_IDS[dtype], _lib.MODE_IDS[mode], device))
         _lib.track(self)
         self.N = 0
-        if mode == "throughput" and steps_per_epoch != 1:
-            _lib.check(self.L.cymf_bpr_set_steps_per_epoch(self.h, int(steps_per_epoch)))
+        if mode == "throughput" and steps_per_epoch != 1:      # None / 0: chosen from the data at set_data
+            _lib.check(self.L.cymf_bpr_set_steps_per_epoch(self.h, int(steps_per_epoch or 0)))
         if comm is not None:
             _lib.check(self.L.cymf_bpr_attach_comm(self.h, comm.h))
+
+    def steps_per_epoch(self):
+        n = C.c_int32(0)
+        _lib.check(self.L.cymf_bpr_get_steps_per_epoch(self.h, C.byref(n)))
+        return n.value
 
     def set_user_bounds(self, bounds):
         """User ranges of all ranks (world + 1 boundaries): download() then returns every rank's rows of W on every rank."""

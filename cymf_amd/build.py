@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 SO = os.path.join(HERE, "libcymf_hip.so")
-SOURCES = ["core.hip", "rng.hip", "bpr.hip", "sgd_models.hip", "relmf_tiles.hip", "wmf.hip", "comm.hip", "eval.hip", "expomf.hip"]
+SOURCES = ["core.hip", "rng.hip", "bpr.hip", "bpr_groups.hip", "sgd_models.hip", "relmf_tiles.hip", "wmf.hip", "comm.hip", "eval.hip", "expomf.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

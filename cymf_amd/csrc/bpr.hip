@@ -15,6 +15,7 @@
 //                     float atomic add of its delta; W[u] and H[j] rows are gathered ahead and
 //                     written back in place.
 #include "store.h"
+#include "bpr_groups.h"
 
 #include <algorithm>
 #include <chrono>
@@ -747,12 +748,16 @@ struct cymf_bpr {
 
     // throughput mode
     int32_t steps_per_epoch = 1;
+    bool steps_auto = false;              // steps_per_epoch = 0 was asked for: chosen from the data (choose_steps_per_epoch)
     int32_t max_waves = 256 * 12;         // hardware side: 12 wavefronts per CU (measured plateau on C3)
     double f_item_max = 0.0;              // share of the triplets that carry the most popular positive item
     int32_t rows_per_inflight = 8;        // staleness bound: table rows per row in flight
     bool item_aligned = false;            // experiment: AdaGrad/Adam item runs owned by one wave (CYMF_BPR_ITEM_ALIGNED=1)
     int32_t adaptive_rpi_factor = 2;      // AdaGrad/Adam: stricter rows-in-flight bound (state RMW is not atomic)
     int32_t step_pf = 84;                 // prefetch ring depth of the step kernel (8 or 16)
+    int32_t group_mode = -1;              // small tables: the group kernel (bpr_groups.hip).  -1 = when the bound on the rows in flight,
+                                          // not the chip, would size the step kernel's launch; 0 / 1 = CYMF_BPR_GROUPS
+    int32_t group_waves = 0;              // its wavefronts (0 = default by optimizer; CYMF_BPR_GROUP_WAVES)
     int32_t xcd_stride = 1;               // diagnostic (CYMF_BPR_XCD_STRIDE=8: all active blocks on one XCD)
     std::vector<int64_t> step_off;           // slot offsets, steps_per_epoch+1
     DevBuf<int32_t> d_slot_user, d_slot_item, d_slot_neg[2];   // slot_neg double-buffered by epoch parity
@@ -1193,12 +1198,66 @@ int ensure_wave_ranges(cymf_bpr *h, int64_t waves_target) {
     return 0;
 }
 
-int run_one_step(cymf_bpr *h) {
+// Small tables run the group kernel (bpr_groups.hip: four triplets per wavefront, every write-back an atomic delta).  Chosen
+// when the step kernel's bound on the rows in flight would leave it a fraction of the wavefronts the chip holds (C2: 94 of
+// 3 072) and the atomics' bytes are small (both tables inside 64 MB); never under a communicator (the multi-GPU exchange is
+// built around the step kernel's item-sorted steps).
+bool group_kernel_fits(const cymf_bpr *h) {   // by shape alone (what the choice of steps_per_epoch is based on)
+    if (h->comm || h->dtype != CYMF_F32 || !bpr_group_supported(h->K)) return false;
+    if (h->group_mode >= 0) return h->group_mode == 1;
+    const int64_t rpi = (int64_t)h->rows_per_inflight * (h->opt == CYMF_OPT_SGD ? 1 : h->adaptive_rpi_factor);
+    const int64_t by_rows = std::max<int64_t>(1, std::min<int64_t>(h->I / (rpi * 4), h->U / (rpi * 4)));
+    return by_rows * 2 < h->max_waves && ((int64_t)h->U + h->I) * h->K * (int64_t)sizeof(float) <= ((int64_t)64 << 20);
+}
+// ... and by the windows the caller chose: the groups work a window's run of one item concurrently, from about the same value of
+// its row; a long run is a mini-batch large enough to overshoot (C2 SGD, hottest item's run per window 5 858 slots: the loss
+// diverges; 1 464: norm of H +7 %; 366: -4.5 %; Adam, whose step does not shrink with the gradient, loses its way at a few
+// hundred) -- such a layout stays on the step kernel, whose few wavefronts walk a run sequentially.  The automatic
+// steps_per_epoch keeps the run at 128 slots or fewer.
+bool use_group_kernel(const cymf_bpr *h) {
+    if (!group_kernel_fits(h)) return false;
+    if (h->group_mode == 1) return true;
+    return h->f_item_max * (double)h->N <= (h->opt == CYMF_OPT_ADAM ? 128.0 : 512.0) * (double)h->steps_per_epoch;
+}
+
+// one step -- or, with the group kernel, `fuse` consecutive steps of the epoch in ONE launch: its groups walk the (step, item)-
+// sorted slots interleaved, so the launch moves through the steps' windows in order by itself
+int run_one_step(cymf_bpr *h, int32_t fuse = 1) {
     CYMF_TRY(ensure_epoch_sampled(h));
     const int32_t s = h->step_cursor;
-    const int64_t b = h->step_off[s], e = h->step_off[s + 1];
+    const bool groups = use_group_kernel(h);
+    if (!groups) fuse = 1;
+    fuse = std::max<int32_t>(1, std::min<int32_t>(fuse, h->steps_per_epoch - s));
+    const int64_t b = h->step_off[s], e = h->step_off[s + fuse];
     BprDev<float> d = h->f32.view(h->K, h->wd, h->lr);
-    if (e > b) {
+    if (e > b && groups) {
+        hipEvent_t p0 = nullptr, p1 = nullptr;
+        if (h->profiling) {
+            if (h->prof_pool.size() >= 2) {
+                p0 = h->prof_pool.back(); h->prof_pool.pop_back();
+                p1 = h->prof_pool.back(); h->prof_pool.pop_back();
+            } else {
+                CYMF_HIP(hipEventCreate(&p0)); CYMF_HIP(hipEventCreate(&p1));
+            }
+            CYMF_HIP(hipEventRecord(p0, h->stream));
+        }
+        BprGroupDev gd{d.W, d.H, d.W0, d.W1, d.H0, d.H1, d.K, d.wd, d.opt};
+        // wavefronts = triplets in flight (4 groups x 16-slot blocks each): one per CU outruns the atomics' rate for SGD / AdaGrad;
+        // small data sets get fewer (the front should stay a few percent of an epoch), and Adam -- whose first moment remembers
+        // ten updates -- about half a percent of an epoch (measurements: bpr_groups.hip header)
+        const int64_t slots_per_wave = h->opt == CYMF_OPT_ADAM ? 12800 : 1024;
+        const int n_waves = h->group_waves > 0 ? h->group_waves
+                                               : (int)std::max<int64_t>(1, std::min<int64_t>(h->opt == CYMF_OPT_ADAM ? 512 : 256, h->N / slots_per_wave));
+        CYMF_TRY(bpr_group_launch(h->opt, gd, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, n_waves,
+                                  h->d_loss.p, h->d_performed.p, h->stream));
+        if (h->profiling) {
+            CYMF_HIP(hipEventRecord(p1, h->stream));
+            h->prof_events.emplace_back(p0, p1);
+            h->prof_launches += 1;
+            h->prof_units += e - b;
+        }
+        h->slots_done += e - b;
+    } else if (e > b) {
         const int64_t chunks = (e - b + 63) / 64;
         // Number of wavefronts = bounded staleness (see the kernel header): at most `max_waves` from
         // the hardware side, and few enough that the rows in flight (waves * PF) stay a small
@@ -1285,7 +1344,7 @@ int run_one_step(cymf_bpr *h) {
                            h->d_delta_scale.p + (size_t)s * h->I, h->K, n);
         CYMF_HIP(hipGetLastError());
     }
-    h->step_cursor++;
+    h->step_cursor += fuse;
     if (h->step_cursor >= h->steps_per_epoch) {
         CYMF_HIP(hipEventRecord(h->ev_epoch_done[(int)(h->epoch_cursor & 1)], h->stream));
         h->step_cursor = 0;
@@ -1356,8 +1415,37 @@ int build_delta_scales(cymf_bpr *h, const std::vector<int32_t> &slot_item) {
     return 0;
 }
 
+bool group_kernel_fits(const cymf_bpr *h);
+
+// steps_per_epoch = 0 ("auto").  The reference trains in the shuffled order (cymf/bpr.pyx:104,162-169); a step is a window of that
+// order inside which the triplets are bucketed by positive item, so the more windows, the closer to the reference's order.
+//  * group kernel (small tables): all of a window's triplets of one item are worked at about the same time, from about the same
+//    value of its row -- the hottest item's run per window is what has to stay small.  Measured on C2 against the sequential
+//    oracle in the reference's order (tools/order_fidelity.py): runs of 5 858 / 1 464 slots diverge /
+//    cost 7 % of the norm of H, 366 slots 4.5 %, 91 slots 0.6 % -> at most 128 slots of the hottest item per window, at least 16
+//    windows, windows of at least 2 048 slots.
+//  * step kernel (large tables): windows of ~5 M triplets of the global order (the size bench.py's headline runs at: a launch
+//    long enough to fill the chip), the same on every rank of a sharded job.
+int32_t choose_steps_per_epoch(const cymf_bpr *h, int64_t hottest_item_count) {
+    const int64_t n_global = std::max<int64_t>(h->N_global, 1);
+    if (group_kernel_fits(h)) {
+        int64_t S = 16;
+        while (S < 4096 && hottest_item_count > 128 * S) S *= 2;
+        while (S > 1 && n_global / S < 2048) S /= 2;
+        return (int32_t)S;
+    }
+    return (int32_t)std::max<int64_t>(1, std::min<int64_t>(4096, (n_global + 2500000) / 5000000));
+}
+
 int build_throughput_layout(cymf_bpr *h) {
     const int64_t N = h->N;
+    if (h->steps_auto) {
+        std::vector<int64_t> c((size_t)h->I, 0);
+        for (int64_t l = 0; l < N; ++l) c[(size_t)h->h_pos_items[l]]++;
+        int64_t mx = 0;
+        for (int64_t v : c) mx = std::max(mx, v);
+        h->steps_per_epoch = choose_steps_per_epoch(h, mx);
+    }
     const int32_t S = h->steps_per_epoch;
     // step of a triplet = window of the GLOBAL order it falls into; slots sorted by (step, item)
     auto step_of = [&](int64_t l) -> int32_t {
@@ -1492,15 +1580,24 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
     if (const char *e8 = getenv("CYMF_BPR_ADAPTIVE_RPI")) h->adaptive_rpi_factor = std::max(1, atoi(e8));
     if (const char *e5 = getenv("CYMF_BPR_HOT_THRESHOLD")) h->hot_threshold = std::max(1, atoi(e5));
     if (const char *e1 = getenv("CYMF_BPR_MAX_WAVES")) h->max_waves = std::max(1, atoi(e1));
+    if (const char *eg = getenv("CYMF_BPR_GROUPS")) h->group_mode = atoi(eg) ? 1 : 0;
+    if (const char *ew = getenv("CYMF_BPR_GROUP_WAVES")) h->group_waves = std::max(1, atoi(ew));
     if (const char *e2 = getenv("CYMF_BPR_ROWS_PER_INFLIGHT")) h->rows_per_inflight = std::max(1, atoi(e2));
     *out = h;
     return 0;
 }
 
 extern "C" int cymf_bpr_set_steps_per_epoch(cymf_bpr *h, int32_t steps) {
-    if (!h || steps < 1) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_steps_per_epoch: bad arguments");
+    if (!h || steps < 0) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_steps_per_epoch: bad arguments");
     if (h->have_data) return fail(CYMF_ERR_INVALID, "cymf_bpr_set_steps_per_epoch must precede cymf_bpr_set_data");
-    h->steps_per_epoch = steps;
+    h->steps_auto = steps == 0;          // 0: chosen from the data at cymf_bpr_set_data (choose_steps_per_epoch)
+    h->steps_per_epoch = steps == 0 ? 1 : steps;
+    return 0;
+}
+
+extern "C" int cymf_bpr_get_steps_per_epoch(cymf_bpr *h, int32_t *steps) {
+    if (!h || !steps) return fail(CYMF_ERR_INVALID, "cymf_bpr_get_steps_per_epoch: bad arguments");
+    *steps = h->steps_per_epoch;
     return 0;
 }
 
@@ -1626,7 +1723,11 @@ extern "C" int cymf_bpr_steps(cymf_bpr *h, int32_t n_steps, double *loss_sum_out
     if (h->mode != CYMF_MODE_THROUGHPUT) return fail(CYMF_ERR_INVALID, "cymf_bpr_steps needs CYMF_MODE_THROUGHPUT");
     CYMF_TRY(use_device(h->device));
     if (loss_sum_out) CYMF_TRY(h->d_loss.zero(h->stream));
-    for (int32_t s = 0; s < n_steps; ++s) CYMF_TRY(run_one_step(h));
+    for (int32_t s = 0; s < n_steps;) {
+        const int32_t before = h->step_cursor;
+        CYMF_TRY(run_one_step(h, n_steps - s));
+        s += (h->step_cursor == 0 ? h->steps_per_epoch : h->step_cursor) - before;   // (the cursor wraps at the end of an epoch)
+    }
     if (loss_sum_out) CYMF_TRY(fetch_loss(h, loss_sum_out));
     return 0;
 }

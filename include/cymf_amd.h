@@ -97,9 +97,12 @@ int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_t *positive
                       const int32_t *indptr, const int32_t *indices,
                       const int64_t *global_pos, int64_t N_global);
 /* THROUGHPUT mode: number of steps an epoch is cut into (windows of the global order).
- * Default 1.  With a communicator attached the item-factor deltas of all ranks are
+ * Default 1; 0 = auto (see cymf_bpr_get_steps_per_epoch).  With a communicator attached the item-factor deltas of all ranks are
  * summed after every step (RCCL all-reduce).  Call before cymf_bpr_set_data. */
 int cymf_bpr_set_steps_per_epoch(cymf_bpr *h, int32_t steps);
+/* steps = 0 above asks for "auto": chosen from the data at cymf_bpr_set_data -- enough windows that the lock-free mode follows
+ * the reference's shuffled order (cymf/bpr.pyx:104) closely; this returns the number in use. */
+int cymf_bpr_get_steps_per_epoch(cymf_bpr *h, int32_t *steps);
 int cymf_bpr_upload(cymf_bpr *h, const double *W, const double *H);       /* H2D, W:(U,K) H:(I,K) */
 int cymf_bpr_download(cymf_bpr *h, double *W, double *H);                 /* D2H */
 /* n_epochs passes of cymf/bpr.pyx:160-171; loss_out[e] = accum_loss / N (:171), may be NULL */

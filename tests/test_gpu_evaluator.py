@@ -149,7 +149,7 @@ def test_bpr_recall_matches_sequential_reference_and_early_stopping():
     mt = BPR(K, 0.01, "adam", 0.01)
     mt.fit(Xtr, num_epochs=30, num_threads=8, verbose=False)
     hog = ev.evaluate(mt.W, mt.H)
-    assert abs(hog["Recall@5"] - ref["Recall@5"]) < 0.02
+    assert abs(hog["Recall@5"] - ref["Recall@5"]) < 0.015    # (within 0.01 at the bars of tests/test_gpu_order_fidelity.py's split)
     assert ref["Recall@5"] > 3 * ev.evaluate(*oracle.reference_init(943, 1682, K))["Recall@5"] or ref["Recall@5"] > 0.1
     # evaluator hook + early stopping
     me = BPR(K, 0.01, "adam", 0.01)
