@@ -305,8 +305,19 @@ def main():
     del trainer
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and not pretend:
+        c3_adam = None
+        if args.optimizer != "adam":
+            # the reference's DEFAULT optimizer (cymf/bpr.pyx:50) on the headline workload: same data, same steps, same timing
+            try:
+                c3_adam = timed_steps(U, I, K, "adam", 0.002, wd, device, spe, users, positives, csr_indptr, csr_indices, nnz, W0, H0,
+                                      args.warmup, args.steps, args.config)
+            except Exception as e:   # pragma: no cover
+                c3_adam = {"error": f"{type(e).__name__}: {e}"}
+            log(0, f"secondary C3_bpr_adam_k128: {c3_adam.get('value', c3_adam.get('error'))}")
         del data, users, positives, W0, H0
         secondary = secondary_paths(device, args.scale)
+        if c3_adam is not None:
+            secondary = {"C3_bpr_adam_k128": c3_adam, **secondary}
 
     if rank == 0 and pretend:
         print(json.dumps({"diagnostic": f"rank 0 of a pretended {pretend}-rank job, one-rank communicator (no exchange traffic)",
@@ -359,6 +370,35 @@ def main():
                       ignore_errors=True)
 
 
+def timed_steps(U, I, K, opt, lr, wd, device, spe, users, positives, indptr, indices, nnz, W0, H0, warmup, steps, config):
+    """N = 1: `steps` timed steps of the lock-free step kernel on the headline data with another optimizer -- the headline's own
+    timing rule (both streams drained on either side, HIP events on the kernel's stream for the roofline)."""
+    bpt = {"sgd": 24, "adagrad": 48, "adam": 72}[opt] * K + 12
+    t = BprTrainer(U, I, K, opt, lr, wd, dtype="float32", mode="throughput", device=device, steps_per_epoch=spe)
+    try:
+        t.set_data(users, positives, indptr, indices, None, nnz)
+        t.upload(W0, H0)
+        t.steps(warmup)
+        t.sync()
+        p0, _ = t.stats()
+        t.set_profiling(True)
+        t.kernel_time()
+        t.sync()
+        t0 = time.perf_counter()
+        t.steps(steps)
+        t.sync()
+        dt = time.perf_counter() - t0
+        p1, _ = t.stats()
+        k_ms, k_n, _ = t.kernel_time()
+    finally:
+        t.close()
+    a = bpt * (p1 - p0) / max(k_n, 1) / max(k_ms / 1e3 / max(k_n, 1), 1e-12)
+    return {"workload": f"{config}: {U} x {I}, {nnz} interactions, K={K}, {opt} lr={lr} wd={wd}, lock-free mode, {spe} steps per epoch",
+            "value": (p1 - p0) / dt, "unit": "triplet-updates/s", "ms": 1e3 * dt / steps, "kernel_ms": k_ms / max(k_n, 1),
+            "roofline": {"bound": "hbm", "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": a / HBM_PEAK, "bytes_per_unit": bpt,
+                         "kernel": "bpr_step_kernel", "traffic": None, "timing": "HIP events on the kernel's stream, average launch"}}
+
+
 # ------------------------------------------------------------------------------------------------ secondary configs
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, MI355X_MICROARCH.md chip table (fp32 matrix = fp32 vector rate)
 
@@ -403,30 +443,41 @@ def secondary_paths(device, scale=1.0):
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         log(0, f"secondary {name}: {time.time()-t0:.1f}s {out[name].get('value', out[name].get('error'))}")
 
-    def c2_bpr():
-        # BASELINE config 2: MovieLens-1M-shaped BPR K=64 fp32 (cymf/bpr.pyx:160-171), lock-free mode
+    def c2_bpr(opt="sgd", lr=0.05):
+        # BASELINE config 2: MovieLens-1M-shaped BPR K=64 fp32 (cymf/bpr.pyx:160-171), lock-free mode, as fit(num_threads != 1)
+        # runs it: steps_per_epoch chosen from the data (windows of the shuffled order), one launch per epoch on this table size
         X, K = synthetic.config_matrix("C2")
         U, I = X.shape
         r, c = X.nonzero()
         perm = np.random.RandomState(5).permutation(len(r))
         W, H = init(U, I, K)
-        t = BprTrainer(U, I, K, "sgd", 0.05, 0.01, dtype="float32", mode="throughput", device=device)
+        t = BprTrainer(U, I, K, opt, lr, 0.01, dtype="float32", mode="throughput", device=device, steps_per_epoch=None)
         t.set_data(r[perm], c[perm], X.indptr, X.indices)
+        S = t.steps_per_epoch()
         t.upload(W, H)
         t.epochs(3)
         p0, _ = t.stats()
         t.set_profiling(True)
         t.kernel_time()
         n = 50
-        ms = _timed_epochs(lambda k: t.steps(k), n, device)
+        ms = _timed_epochs(lambda k: t.steps(k * S), n, device)
         p1, _ = t.stats()
         k_ms, k_n, _ = t.kernel_time()
         t.close()
         per_epoch = (p1 - p0) / (n + 1)
-        rl = _hbm_roofline(per_epoch, 24 * K + 12, k_ms / max(k_n, 1), "bpr_step_kernel")
-        rl["timing"] = "HIP events on the kernel's stream, average launch"
-        return {"workload": f"C2: {U} x {I}, {X.nnz} interactions, K={K}, sgd, lock-free mode, one step per epoch",
-                "value": per_epoch / (ms * 1e-3), "unit": "triplet-updates/s", "ms": ms, "kernel_ms": k_ms / max(k_n, 1), "roofline": rl}
+        bpt = {"sgd": 24, "adagrad": 48, "adam": 72}[opt] * K + 12
+        k_epoch_ms = k_ms / (n + 1)                      # all launches of an epoch (one, with the group kernel)
+        rl = _hbm_roofline(per_epoch, bpt, k_epoch_ms, "bpr_group_kernel" if k_n <= n + 1 else "bpr_step_kernel")
+        rl["timing"] = "HIP events on the kernel's stream, launches of one epoch"
+        rl["launches_per_epoch"] = k_n / (n + 1)
+        # what bounds it: every write-back is a float-atomic delta executed at the memory side (~1.3 TB/s chip-wide,
+        # MI355X_MICROARCH.md 'Global float atomics'): W[u] and H[j] per triplet, H[i] once per run of its item inside a block
+        rl["atomic_bound_note"] = ("bound by the memory-side float-atomic rate (~1300 GB/s), not by HBM: >= 2 rows of "
+                                   f"{4 * K} B per triplet are added atomically")
+        rl["atomic_GBps_min"] = per_epoch * 2 * 4 * K * (2 if opt == "adagrad" else (1.5 if opt == "adam" else 1)) / (k_epoch_ms * 1e-3) / 1e9
+        return {"workload": f"C2: {U} x {I}, {X.nnz} interactions, K={K}, {opt} lr={lr}, lock-free mode, steps_per_epoch={S} (fit()'s default)",
+                "value": per_epoch / (ms * 1e-3), "unit": "triplet-updates/s", "ms": ms, "kernel_ms": k_epoch_ms, "steps_per_epoch": S,
+                "roofline": rl}
 
     def c4_wmf():
         # BASELINE config 4: WMF ALS K=64 on ml-20m-shaped data (cymf/wmf.pyx:150-171)
@@ -492,6 +543,7 @@ def secondary_paths(device, scale=1.0):
                 "unit": "draws/s", "ms": ms, "roofline": _hbm_roofline(U * I, 16 * K + 8, ms, "relmf step kernels")}
 
     attempt("C2_bpr_k64", c2_bpr)
+    attempt("C2_bpr_adam_k64", lambda: c2_bpr("adam", 0.002))     # the reference's default optimizer (cymf/bpr.pyx:50)
     attempt("C4_wmf_k64", c4_wmf)
     attempt("C5_glove_k100", c5_glove)
     attempt("relmf_20000x8000_k64", relmf)

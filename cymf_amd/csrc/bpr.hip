@@ -266,13 +266,6 @@ __global__ __launch_bounds__(256) void bpr_ticket_kernel(BprDev<T> d, const int3
 // linear probing): a membership test is a single 64-byte sector read almost always, where a binary
 // search of the user's CSR row costs log2(n_u) dependent sector reads (measured: 93 GB of fetches
 // per 100M-slot epoch, more than a third of what all step kernels of the epoch move).
-constexpr unsigned long long PAIR_EMPTY = ~0ull;
-
-__device__ __forceinline__ unsigned long long pair_hash(unsigned long long k) {   // murmur3 finalizer
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-    return k;
-}
-
 __global__ __launch_bounds__(256) void pair_table_build_kernel(const int32_t *__restrict__ indptr,
                                                               const int32_t *__restrict__ indices, int32_t U,
                                                               unsigned long long *__restrict__ table,
@@ -311,15 +304,7 @@ __global__ __launch_bounds__(256) void bpr_sample_kernel(const int32_t *__restri
     for (; t < n; t += stride) {
         const int32_t u = slot_user[t];
         const int32_t j = (int32_t)draws[slot_pos[t]];
-        const unsigned long long key = ((unsigned long long)(unsigned int)u << 32) | (unsigned int)j;
-        unsigned long long slot = pair_hash(key) & mask;
-        bool found = false;
-        while (true) {
-            const unsigned long long v = table[slot];
-            if (v == key) { found = true; break; }
-            if (v == PAIR_EMPTY) break;
-            slot = (slot + 1) & mask;
-        }
+        const bool found = pair_table_has(table, mask, u, j);
         // bit 30 marks a negative that is a HOT item (many positive-side exchanges per step): the step
         // kernel adds its delta atomically instead of storing the row back
         const int32_t hot = (int32_t)((hot_bits[j >> 5] >> (j & 31)) & 1u) << 30;
@@ -709,6 +694,8 @@ struct cymf_bpr {
     double lr = 0, wd = 0;
     uint32_t seed = 1234;
     hipStream_t stream = nullptr, rng_stream = nullptr;
+    hipStream_t gen_stream = nullptr;                          // batched index-stream generation (draw_batch > 1), beside the sampling
+    hipEvent_t ev_batch_sampled[2] = {nullptr, nullptr};       // the last epoch of a batch of draws has been sampled (buffer reusable)
     BprStore<float> f32;
     BprStore<double> f64;
     bool have_params = false, have_data = false;
@@ -725,6 +712,7 @@ struct cymf_bpr {
     DeviceRng rng;
     bool rng_ready = false;
     DevBuf<uint32_t> d_draws[2];
+    int64_t draw_batch = 1;         // epochs generated per call of the index-stream generator (see request_epoch_draws)
     hipEvent_t ev_gen[2] = {nullptr, nullptr}, ev_sampled[2] = {nullptr, nullptr};
     int64_t epochs_generated = 0;   // draws of epochs [0, epochs_generated) have been requested
     int64_t epoch_cursor = 0;       // next epoch to train
@@ -954,17 +942,30 @@ int finish_exchange(cymf_bpr *h, bool snapshot_if_idle, const float *local_cur =
     return 0;
 }
 
-// ---- negatives of epoch `e` into d_draws[e & 1]; generated in stream order on rng_stream
+// ---- the draws of epoch `e`, generated in stream order on rng_stream.  The stream is ONE generator that is never reseeded
+// (cymf/bpr.pyx:141): epoch e owns draws [e N, (e + 1) N).  Large epochs are generated one at a time into d_draws[e & 1].  A small
+// epoch (ml-1m-shaped: 466 k draws) would be walked by ONE workgroup in ~0.8 ms -- three times what the group kernel needs for
+// the epoch's triplets -- so the lock-free mode generates `draw_batch` epochs per call with the chunked jump-ahead generator
+// (>= 4 M draws: enough chunks to spread over the chip) into d_draws[(e / draw_batch) & 1]; an epoch is a slice of its batch.
+const uint32_t *epoch_draws(const cymf_bpr *h, int64_t e) {
+    return h->d_draws[(int)((e / h->draw_batch) & 1)].p + (size_t)(e % h->draw_batch) * (size_t)h->N_global;
+}
+
 int request_epoch_draws(cymf_bpr *h, int64_t e) {
     while (h->epochs_generated <= e) {
-        const int64_t g = h->epochs_generated;
-        const int b = (int)(g & 1);
-        CYMF_TRY(h->d_draws[b].alloc((size_t)h->N_global));
-        // buffer b was last read by the sampling of epoch g-2
-        if (g >= 2) CYMF_HIP(hipStreamWaitEvent(h->rng_stream, h->ev_sampled[b], 0));
-        CYMF_TRY(h->rng.generate(0, h->N_global, h->d_draws[b].p, h->rng_stream));
-        CYMF_HIP(hipEventRecord(h->ev_gen[b], h->rng_stream));
-        h->epochs_generated++;
+        const int64_t g = h->epochs_generated, E = h->draw_batch;
+        const int64_t q = g / E;
+        const int b = (int)(q & 1);
+        CYMF_TRY(h->d_draws[b].alloc((size_t)h->N_global * (size_t)E));
+        hipStream_t gs = E > 1 ? h->gen_stream : h->rng_stream;
+        // buffer b was last read by the sampling of epoch g - 2 (E == 1) / of the last epoch of batch q - 2 (batches: their
+        // generation runs on its own stream, a whole batch ahead of its first use, so that it never stands in front of a sampling
+        // kernel the step stream is waiting for)
+        if (E == 1 && g >= 2) CYMF_HIP(hipStreamWaitEvent(gs, h->ev_sampled[b], 0));
+        if (E > 1 && q >= 2) CYMF_HIP(hipStreamWaitEvent(gs, h->ev_batch_sampled[b], 0));
+        CYMF_TRY(h->rng.generate(0, h->N_global * E, h->d_draws[b].p, gs));
+        CYMF_HIP(hipEventRecord(h->ev_gen[b], gs));
+        h->epochs_generated += E;
     }
     return 0;
 }
@@ -988,7 +989,7 @@ int exact_fetch_draws(cymf_bpr *h, int64_t g) {
             CYMF_HIP(hipHostMalloc((void **)&h->h_draws2[b], (size_t)std::max<int64_t>(h->N_global, 1) * sizeof(uint32_t)));
             h->h_draws_cap[b] = h->N_global;
         }
-        CYMF_HIP(hipMemcpyAsync(h->h_draws2[b], h->d_draws[b].p, (size_t)h->N_global * sizeof(uint32_t), hipMemcpyDeviceToHost, h->rng_stream));
+        CYMF_HIP(hipMemcpyAsync(h->h_draws2[b], epoch_draws(h, q), (size_t)h->N_global * sizeof(uint32_t), hipMemcpyDeviceToHost, h->rng_stream));
         CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->rng_stream));     // d_draws[b] may be regenerated after this copy
         CYMF_HIP(hipEventRecord(h->ev_draws_host[b], h->rng_stream));
         h->exact_fetched++;
@@ -1138,21 +1139,34 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
 // Negatives of epoch e: generate (rng.hip) and resolve against the users' positives, both on the
 // rng stream, into the buffers of parity e & 1 -- one epoch ahead of the step kernels, so that the
 // whole sampling pipeline of epoch e+1 runs concurrently with the steps of epoch e.
+bool use_group_kernel(const cymf_bpr *h);
+// small epochs on the group kernel: the negatives are resolved inside it (BprGroupSample), no sampling kernel, no second stream
+// between the generator and the steps
+bool fused_sampling(const cymf_bpr *h) { return h->draw_batch > 1 && use_group_kernel(h); }
+
 int prepare_epoch(cymf_bpr *h, int64_t e) {
     while (h->epochs_sampled <= e) {
         const int64_t g = h->epochs_sampled;
         const int b = (int)(g & 1);
         CYMF_TRY(request_epoch_draws(h, g));
+        const int64_t E = h->draw_batch;
+        if (fused_sampling(h)) {   // the group kernel resolves the negatives itself: nothing to do on the side stream
+            h->epochs_sampled++;     // (the NEXT batch of draws is requested by run_one_step, once the buffer it goes to is free)
+            continue;
+        }
+        if (E > 1) CYMF_HIP(hipStreamWaitEvent(h->rng_stream, h->ev_gen[(int)((g / E) & 1)], 0));
         // slot_neg[b] was last read by the steps of epoch g-2
         if (g >= 2) CYMF_HIP(hipStreamWaitEvent(h->rng_stream, h->ev_epoch_done[b], 0));
         if (h->N > 0) {
             int blocks = (int)std::min<int64_t>((h->N + 255) / 256, 256 * 16);
             hipLaunchKernelGGL(bpr_sample_kernel, dim3(blocks), dim3(256), 0, h->rng_stream, h->d_slot_user.p, h->d_slot_pos.p,
-                               h->d_draws[b].p, h->d_pair_table.p, h->pair_mask, h->d_hot_bits.p, h->d_slot_neg[b].p, h->N,
+                               epoch_draws(h, g), h->d_pair_table.p, h->pair_mask, h->d_hot_bits.p, h->d_slot_neg[b].p, h->N,
                                h->d_skipped.p);
             CYMF_HIP(hipGetLastError());
         }
         CYMF_HIP(hipEventRecord(h->ev_sampled[b], h->rng_stream));
+        if (E > 1 && g % E == E - 1) CYMF_HIP(hipEventRecord(h->ev_batch_sampled[(int)((g / E) & 1)], h->rng_stream));
+        if (E > 1 && g % E == 0) CYMF_TRY(request_epoch_draws(h, g + E));   // the NEXT batch, beside this batch's epochs
         h->epochs_sampled++;
     }
     return 0;
@@ -1162,7 +1176,8 @@ int ensure_epoch_sampled(cymf_bpr *h) {
     if (h->epoch_sampled) return 0;
     const int64_t e = h->epoch_cursor;
     CYMF_TRY(prepare_epoch(h, e));
-    CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_sampled[(int)(e & 1)], 0));
+    if (fused_sampling(h)) CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_gen[(int)((e / h->draw_batch) & 1)], 0));   // the epoch's draws exist
+    else CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_sampled[(int)(e & 1)], 0));
     h->epoch_sampled = true;
     CYMF_TRY(prepare_epoch(h, e + 1));   // next epoch's negatives, concurrently with this epoch's steps
     return 0;
@@ -1242,14 +1257,20 @@ int run_one_step(cymf_bpr *h, int32_t fuse = 1) {
             CYMF_HIP(hipEventRecord(p0, h->stream));
         }
         BprGroupDev gd{d.W, d.H, d.W0, d.W1, d.H0, d.H1, d.K, d.wd, d.opt};
-        // wavefronts = triplets in flight (4 groups x 16-slot blocks each): one per CU outruns the atomics' rate for SGD / AdaGrad;
+        // wavefronts = triplets in flight (4 groups x 16-slot blocks each): one or two per CU reach the atomics' rate for SGD / AdaGrad
+        // (C2: 128 / 256 / 512 / 1 024 wavefronts 0.47 / 0.27 / 0.24 / 0.25 ms per epoch);
         // small data sets get fewer (the front should stay a few percent of an epoch), and Adam -- whose first moment remembers
         // ten updates -- about half a percent of an epoch (measurements: bpr_groups.hip header)
         const int64_t slots_per_wave = h->opt == CYMF_OPT_ADAM ? 12800 : 1024;
         const int n_waves = h->group_waves > 0 ? h->group_waves
-                                               : (int)std::max<int64_t>(1, std::min<int64_t>(h->opt == CYMF_OPT_ADAM ? 512 : 256, h->N / slots_per_wave));
+                                               : (int)std::max<int64_t>(1, std::min<int64_t>(512, h->N / slots_per_wave));
+        BprGroupSample smp;
+        if (fused_sampling(h)) {
+            smp.slot_pos = h->d_slot_pos.p; smp.draws = epoch_draws(h, h->epoch_cursor); smp.table = h->d_pair_table.p;
+            smp.mask = h->pair_mask; smp.slot_neg_out = h->d_slot_neg[(int)(h->epoch_cursor & 1)].p;
+        }
         CYMF_TRY(bpr_group_launch(h->opt, gd, h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, n_waves,
-                                  h->d_loss.p, h->d_performed.p, h->stream));
+                                  h->d_loss.p, h->d_performed.p, h->stream, smp));
         if (h->profiling) {
             CYMF_HIP(hipEventRecord(p1, h->stream));
             h->prof_events.emplace_back(p0, p1);
@@ -1347,6 +1368,14 @@ int run_one_step(cymf_bpr *h, int32_t fuse = 1) {
     h->step_cursor += fuse;
     if (h->step_cursor >= h->steps_per_epoch) {
         CYMF_HIP(hipEventRecord(h->ev_epoch_done[(int)(h->epoch_cursor & 1)], h->stream));
+        if (fused_sampling(h)) {
+            const int64_t ec = h->epoch_cursor, E = h->draw_batch;
+            if (ec % E == E - 1)   // this batch of draws has been consumed: its buffer may be regenerated behind this event
+                CYMF_HIP(hipEventRecord(h->ev_batch_sampled[(int)((ec / E) & 1)], h->stream));
+            // first epoch of a batch done: generate the NEXT batch beside this batch's remaining epochs.  Its buffer was last read by
+            // the previous batch, whose event was recorded (above) before this epoch was launched.
+            if (ec % E == 0) CYMF_TRY(request_epoch_draws(h, ec + E));
+        }
         h->step_cursor = 0;
         h->epoch_cursor++;
         h->epoch_sampled = false;
@@ -1638,8 +1667,18 @@ extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_
     CYMF_TRY(h->d_indices.upload(h->h_indices.data(), h->h_indices.size(), h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
     if (!h->rng_ready) {   // ONE generator for the whole fit (bpr.pyx:141)
-        // >= 2M draws per epoch: chunked jump-ahead generator (rng.hip), else the one-workgroup walker
-        CYMF_TRY(h->rng.init(h->seed, (uint64_t)h->I, h->rng_stream, /*parallel=*/N_global >= (int64_t)2 << 20));
+        // >= 2M draws per epoch: chunked jump-ahead generator (rng.hip).  Smaller epochs: the lock-free mode generates several
+        // epochs per call with that generator (request_epoch_draws); the exact mode, whose epochs take milliseconds of
+        // hand-offs anyway, keeps the one-workgroup walker and one epoch per call.
+        const bool big = N_global >= (int64_t)2 << 20;
+        h->draw_batch = 1;
+        if (!big && h->mode == CYMF_MODE_THROUGHPUT && N_global > 0 && !getenv("CYMF_BPR_NO_DRAW_BATCH"))
+            h->draw_batch = std::max<int64_t>(2, std::min<int64_t>(64, (((int64_t)4 << 20) + N_global - 1) / N_global));
+        if (h->draw_batch > 1 && !h->gen_stream) {
+            CYMF_HIP(hipStreamCreateWithFlags(&h->gen_stream, hipStreamNonBlocking));
+            for (int b = 0; b < 2; ++b) CYMF_HIP(hipEventCreateWithFlags(&h->ev_batch_sampled[b], hipEventDisableTiming));
+        }
+        CYMF_TRY(h->rng.init(h->seed, (uint64_t)h->I, h->draw_batch > 1 ? h->gen_stream : h->rng_stream, /*parallel=*/big || h->draw_batch > 1));
         h->rng_ready = true;
     }
     if (h->mode == CYMF_MODE_THROUGHPUT) CYMF_TRY(build_throughput_layout(h));
@@ -1761,6 +1800,7 @@ extern "C" int cymf_bpr_sync(cymf_bpr *h) {
     CYMF_HIP(hipStreamSynchronize(h->stream));
     // and the side stream: the next epoch's index stream and skip tests are part of the work this handle has issued
     if (h->rng_stream) CYMF_HIP(hipStreamSynchronize(h->rng_stream));
+    if (h->gen_stream) CYMF_HIP(hipStreamSynchronize(h->gen_stream));
     return 0;
 }
 
@@ -1840,6 +1880,8 @@ extern "C" int cymf_bpr_destroy(cymf_bpr *h) {
     if (!cymf::runtime_alive(h->device)) return 0;   // process exit / runtime already torn down: leak quietly
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->rng_stream) (void)hipStreamSynchronize(h->rng_stream);
+    if (h->gen_stream) { (void)hipStreamSynchronize(h->gen_stream); (void)hipStreamDestroy(h->gen_stream); }
+    for (int b = 0; b < 2; ++b) if (h->ev_batch_sampled[b]) (void)hipEventDestroy(h->ev_batch_sampled[b]);
     for (auto &pe : h->prof_events) { (void)hipEventDestroy(pe.first); (void)hipEventDestroy(pe.second); }
     for (auto &e : h->prof_pool) (void)hipEventDestroy(e);
     for (int b = 0; b < 2; ++b) {

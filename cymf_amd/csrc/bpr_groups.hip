@@ -104,7 +104,8 @@ template <int E, bool FULL, int OPT, int PF>
 __global__ __launch_bounds__(64) void bpr_group_kernel(BprGroupDev d, const int32_t *__restrict__ slot_user,
                                                       const int32_t *__restrict__ slot_item, const int32_t *__restrict__ slot_neg,
                                                       int64_t slot_begin, int64_t slot_end, int64_t n_groups,
-                                                      double *__restrict__ loss_acc, unsigned long long *__restrict__ performed_acc) {
+                                                      double *__restrict__ loss_acc, unsigned long long *__restrict__ performed_acc,
+                                                      BprGroupSample smp) {
     constexpr int NS = opt_num_states(OPT);
     constexpr int NSA = NS ? NS : 1;
     constexpr int RING = 2 * PF;
@@ -126,7 +127,16 @@ __global__ __launch_bounds__(64) void bpr_group_kernel(BprGroupDev d, const int3
         const bool in = it < n_iter && blk < n_blocks && s < slot_end;
         u = in ? slot_user[s] : 0;
         i = in ? slot_item[s] : 0;
-        j = in ? slot_neg[s] : -1;
+        if (smp.draws) {   // wave-uniform: the negatives are resolved here (three dependent reads, two blocks ahead of their use)
+            j = -1;
+            if (in) {
+                const int32_t draw = (int32_t)smp.draws[smp.slot_pos[s]];
+                j = pair_table_has(smp.table, smp.mask, u, draw) ? -1 : draw;
+                smp.slot_neg_out[s] = j;
+            }
+        } else {
+            j = in ? slot_neg[s] : -1;
+        }
         if (j < 0) { u = 0; i = 0; }
     };
     int32_t u_c, i_c, j_c, u_n, i_n, j_n;
@@ -278,20 +288,20 @@ __global__ __launch_bounds__(64) void bpr_group_kernel(BprGroupDev d, const int3
 
 template <int E, bool FULL, int OPT>
 void launch_inst(const BprGroupDev &d, const int32_t *su, const int32_t *si, const int32_t *sn, int64_t b, int64_t e, int n_waves,
-                 double *loss, unsigned long long *perf, hipStream_t s) {
+                 double *loss, unsigned long long *perf, hipStream_t s, const BprGroupSample &smp) {
     // rows held per ring entry: 3 (1 + states) E values per lane; the ring is sized to ~256 registers
     constexpr int per_entry = 3 * (1 + opt_num_states(OPT)) * E;
     constexpr int PF = per_entry <= 16 ? 8 : (per_entry <= 32 ? 4 : 2);
-    hipLaunchKernelGGL((bpr_group_kernel<E, FULL, OPT, PF>), dim3(n_waves), dim3(64), 0, s, d, su, si, sn, b, e, (int64_t)n_waves * GPW, loss, perf);
+    hipLaunchKernelGGL((bpr_group_kernel<E, FULL, OPT, PF>), dim3(n_waves), dim3(64), 0, s, d, su, si, sn, b, e, (int64_t)n_waves * GPW, loss, perf, smp);
 }
 
 template <int E, bool FULL>
 void launch_opt(int opt, const BprGroupDev &d, const int32_t *su, const int32_t *si, const int32_t *sn, int64_t b, int64_t e,
-                int n_waves, double *loss, unsigned long long *perf, hipStream_t s) {
+                int n_waves, double *loss, unsigned long long *perf, hipStream_t s, const BprGroupSample &smp) {
     switch (opt) {
-    case CYMF_OPT_SGD: launch_inst<E, FULL, CYMF_OPT_SGD>(d, su, si, sn, b, e, n_waves, loss, perf, s); break;
-    case CYMF_OPT_ADAGRAD: launch_inst<E, FULL, CYMF_OPT_ADAGRAD>(d, su, si, sn, b, e, n_waves, loss, perf, s); break;
-    default: launch_inst<E, FULL, CYMF_OPT_ADAM>(d, su, si, sn, b, e, n_waves, loss, perf, s); break;
+    case CYMF_OPT_SGD: launch_inst<E, FULL, CYMF_OPT_SGD>(d, su, si, sn, b, e, n_waves, loss, perf, s, smp); break;
+    case CYMF_OPT_ADAGRAD: launch_inst<E, FULL, CYMF_OPT_ADAGRAD>(d, su, si, sn, b, e, n_waves, loss, perf, s, smp); break;
+    default: launch_inst<E, FULL, CYMF_OPT_ADAM>(d, su, si, sn, b, e, n_waves, loss, perf, s, smp); break;
     }
 }
 
@@ -299,13 +309,13 @@ void launch_opt(int opt, const BprGroupDev &d, const int32_t *su, const int32_t 
 
 int bpr_group_launch(int opt, const BprGroupDev &d, const int32_t *slot_user, const int32_t *slot_item, const int32_t *slot_neg,
                      int64_t slot_begin, int64_t slot_end, int n_waves, double *loss_acc, unsigned long long *performed_acc,
-                     hipStream_t s) {
+                     hipStream_t s, const BprGroupSample &sample) {
     if (!bpr_group_supported(d.K)) return fail(CYMF_ERR_UNSUPPORTED, "bpr_group_launch: K=%d", d.K);
     if (slot_end <= slot_begin) return 0;
     const int64_t n_blocks = (slot_end - slot_begin + GL - 1) / GL;
     n_waves = (int)std::max<int64_t>(1, std::min<int64_t>(n_waves, (n_blocks + GPW - 1) / GPW));
     const int K = d.K;
-#define GO_(E_, F_) launch_opt<E_, F_>(opt, d, slot_user, slot_item, slot_neg, slot_begin, slot_end, n_waves, loss_acc, performed_acc, s)
+#define GO_(E_, F_) launch_opt<E_, F_>(opt, d, slot_user, slot_item, slot_neg, slot_begin, slot_end, n_waves, loss_acc, performed_acc, s, sample)
     if (K == 64) GO_(4, true);
     else if (K == 128) GO_(8, true);
     else if (K <= 16) GO_(1, false);

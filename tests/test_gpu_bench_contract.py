@@ -36,7 +36,9 @@ def test_bench_line_contract():
     assert r["frac_min_traffic"] < r["frac"] and "traffic_source" in r and "basis" in r
     # BASELINE.json's other configs, driver-visible
     sec = d["secondary"]
-    assert set(sec) == {"C2_bpr_k64", "C4_wmf_k64", "C5_glove_k100", "relmf_20000x8000_k64"}
+    assert set(sec) == {"C3_bpr_adam_k128", "C2_bpr_k64", "C2_bpr_adam_k64", "C4_wmf_k64", "C5_glove_k100", "relmf_20000x8000_k64"}
+    assert "adam" in sec["C3_bpr_adam_k128"]["workload"] and "adam" in sec["C2_bpr_adam_k64"]["workload"]     # the reference's default optimizer (cymf/bpr.pyx:50)
+    assert sec["C2_bpr_k64"]["steps_per_epoch"] >= 16
     for name, e in sec.items():
         assert "error" not in e, (name, e)
         assert e["value"] > 0 and e["ms"] > 0 and e["unit"] and e["workload"]
