@@ -253,12 +253,12 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from rocprofv3 --pmc
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))
-            traffic = tj.get(f"bpr_step_{args.optimizer}_K{K}")
-            if traffic is not None:
-                prof_slots = int(tj.get("slots_per_launch", 4000000))
-                traffic = traffic * (k_slots / max(k_launches, 1)) / prof_slots      # per launch of THIS run's step size
-                traffic_source = ("profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of "
+            tj = json.load(open(tpath)).get("bench", {})
+            ent = tj.get(f"C3_{args.optimizer}") if (args.config == "C3" and K == 128) else None
+            if ent is not None:
+                prof_slots = int(tj.get("c3_slots_per_launch", 5000000))
+                traffic = ent["bytes"] * (k_slots / max(k_launches, 1)) / prof_slots      # per launch of THIS run's step size
+                traffic_source = (f"{tj.get('source')} (static: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of "
                                   f"{prof_slots} slots, scaled to this run's {int(k_slots / max(k_launches, 1))} slots per launch; not measured in this run)")
         except Exception:
             traffic = None
@@ -317,6 +317,9 @@ def main():
         del data, users, positives, W0, H0
         secondary = secondary_paths(device, args.scale)
         if c3_adam is not None:
+            if "roofline" in c3_adam and args.scale == 1.0:
+                t_, src_ = _static_traffic("C3_adam")
+                c3_adam["roofline"]["traffic"], c3_adam["roofline"]["traffic_source"] = t_, src_
             secondary = {"C3_bpr_adam_k128": c3_adam, **secondary}
 
     if rank == 0 and pretend:
@@ -415,6 +418,17 @@ def _timed_epochs(run, n, device):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
+def _static_traffic(key):
+    """HBM bytes of a secondary workload from profiles/traffic.json (rocprofv3 --pmc passes over this very command,
+    tools/profile_bench.sh; static file, not measured in this run): (bytes, what the figure covers)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("bench", {})
+        e = tj.get(key)
+        return (e["bytes"], f"{e['unit']}; {tj.get('source')}, not measured in this run") if e else (None, None)
+    except Exception:
+        return None, None
+
+
 def _hbm_roofline(units, bytes_per_unit, ms, kernel):
     a = units * bytes_per_unit / (ms * 1e-3)
     return {"bound": "hbm", "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": a / HBM_PEAK,
@@ -475,6 +489,7 @@ def secondary_paths(device, scale=1.0):
         rl["atomic_bound_note"] = ("bound by the memory-side float-atomic rate (~1300 GB/s), not by HBM: >= 2 rows of "
                                    f"{4 * K} B per triplet are added atomically")
         rl["atomic_GBps_min"] = per_epoch * 2 * 4 * K * (2 if opt == "adagrad" else (1.5 if opt == "adam" else 1)) / (k_epoch_ms * 1e-3) / 1e9
+        rl["traffic"], rl["traffic_source"] = _static_traffic("C2_" + opt)
         return {"workload": f"C2: {U} x {I}, {X.nnz} interactions, K={K}, {opt} lr={lr}, lock-free mode, steps_per_epoch={S} (fit()'s default)",
                 "value": per_epoch / (ms * 1e-3), "unit": "triplet-updates/s", "ms": ms, "kernel_ms": k_epoch_ms, "steps_per_epoch": S,
                 "roofline": rl}
@@ -500,8 +515,12 @@ def secondary_paths(device, scale=1.0):
             a = flops / (ms * 1e-3)
             res[Kx] = {"workload": f"C4: {U} x {I}, {X.nnz} entries, K={Kx}, weight 10, f32", "value": 1e3 / ms, "unit": "epochs/s", "ms": ms,
                        "roofline": {"bound": "mfma", "achieved": a / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                                    "frac": a / MFMA_F32_PEAK, "flops_per_epoch": flops, "kernel": "wmf_row_reg_kernel (+ seg / long / YtY kernels)",
-                                    "gather_GBps": 2 * X.nnz * (4 * Kx + 4) / (ms * 1e-3) / 1e9, "traffic": None,
+                                    "frac": a / MFMA_F32_PEAK, "flops_per_epoch": flops,
+                                    "kernel": ("wmf_row_reg_kernel<2,1>" if Kx == 64 else "wmf_row_blk_kernel<4>") + " (+ wmf_seg / wmf_long_reg / YtY kernels)",
+                                    "gather_GBps": 2 * X.nnz * (4 * Kx + 4) / (ms * 1e-3) / 1e9,
+                                    "traffic": _static_traffic(f"C4_k{Kx}")[0] if scale == 1.0 else None, "traffic_source": _static_traffic(f"C4_k{Kx}")[1],
+                                    "flops_note": "SURVEY.md 8d prices the full K x K Gramian (2 K^2 nnz per half-sweep); the kernels form the upper tiles only "
+                                                  f"({Kx // 32 * (Kx // 32 + 1) // 2} of {(Kx // 32) ** 2}), so MFMA-executed flops are that fraction of the Gramian term",
                                     "timing": "device-synchronised wall time per epoch (both half-sweeps, all kernels)"}}
         r = res[64]
         r["k128"] = res[128]
@@ -525,7 +544,9 @@ def secondary_paths(device, scale=1.0):
         ms = _timed_epochs(lambda k: t.epochs(k), 5, device)
         t.close()
         return {"workload": f"C5: V={V}, {len(ce)} pairs, K={K}, AdaGrad lr 0.05, lock-free mode", "value": len(ce) / (ms * 1e-3),
-                "unit": "pairs/s", "ms": ms, "roofline": _hbm_roofline(len(ce), 32 * K + 44, ms, "glove_step_kernel")}
+                "unit": "pairs/s", "ms": ms, "roofline": dict(_hbm_roofline(len(ce), 32 * K + 44, ms, "glove_step_kernel"),
+                                                               traffic=_static_traffic("C5_glove")[0] if scale == 1.0 else None,
+                                                               traffic_source=_static_traffic("C5_glove")[1])}
 
     def relmf():
         # RelMF (cymf/relmf.pyx:142-148): U*I uniform cell draws per epoch
@@ -540,7 +561,14 @@ def secondary_paths(device, scale=1.0):
         ms = _timed_epochs(lambda k: t.epochs(k), 4, device)
         t.close()
         return {"workload": f"RelMF {U} x {I} dense, K={K}, sgd, {U*I} draws per epoch, lock-free mode", "value": U * I / (ms * 1e-3),
-                "unit": "draws/s", "ms": ms, "roofline": _hbm_roofline(U * I, 16 * K + 8, ms, "relmf step kernels")}
+                "unit": "draws/s", "ms": ms,
+                "roofline": dict(_hbm_roofline(U * I, 16 * K + 8, ms, "relmf_tile_kernel (+ tile_count / tile_scatter / index-stream kernels)"),
+                                 traffic=_static_traffic("RelMF")[0] if scale == 1.0 else None, traffic_source=_static_traffic("RelMF")[1],
+                                 bound_note="the algorithmic-byte figure is what SURVEY.md 8d defines, not a utilisation: a tile's item rows live in LDS and reach HBM "
+                                            "once per tile (~31 draws per row), so real HBM traffic is ~1/10 of it (`traffic`); the tile kernel is a latency chain "
+                                            "(LDS read -> dot -> DPP sum -> compare-and-swap, ~50 wave-instructions per step of four draws) -- neither the LDS "
+                                            "pipe (~1 KB per draw = 160 GB per epoch against ~79 TB/s) nor instruction issue (~2 G wave-instructions against "
+                                            "2 458 G/s) is within an order of magnitude of its peak")}
 
     attempt("C2_bpr_k64", c2_bpr)
     attempt("C2_bpr_adam_k64", lambda: c2_bpr("adam", 0.002))     # the reference's default optimizer (cymf/bpr.pyx:50)

@@ -577,7 +577,55 @@ __global__ void delta_kernel(const float *__restrict__ H, const float *__restric
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) delta[i] = H[i] - snap[i];
 }
-// scale[row]: the sequentialisation factor of that item for this step (see build_delta_scales)
+constexpr int DELTA_TAIL = 16;   // floats behind the I x K item deltas of an exchange message (the first two: the measured data term)
+
+// Multi-GPU: the data term of the per-touch contraction, MEASURED.  A touch of item row h by user row w moves it by
+// lr s w with s = sigma(-x), x = w . (h - h_j): its Jacobian is -lr sigma'(x) w w^T, a contraction by lr sigma'(x) |w|^2 along w.
+// One wavefront per sampled slot of the step (a stride through the item-sorted slots) forms sigma'(x) |w|^2 from the factors
+// as they stand when the step starts; out[0] += that, out[1] += 1.  The two floats ride at the tail of the item-delta message,
+// so every rank ends with the job-wide sums and computes the same factors (delta_scale_kernel) without a host round trip.
+__global__ __launch_bounds__(256) void bpr_curvature_kernel(const float *__restrict__ W, const float *__restrict__ H, int K,
+                                                           const int32_t *__restrict__ slot_user, const int32_t *__restrict__ slot_item,
+                                                           const int32_t *__restrict__ slot_neg, int64_t b, int64_t e, int64_t n_samples,
+                                                           float *__restrict__ out) {
+    const int lane = lane_id();
+    const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w0 >= n_samples || e <= b) return;
+    const int64_t t = b + (w0 * (e - b)) / n_samples;
+    const int32_t jraw = slot_neg[t];
+    if (jraw < 0) return;
+    const int64_t ou = (int64_t)slot_user[t] * K, oi = (int64_t)slot_item[t] * K, oj = (int64_t)(jraw & 0x3fffffff) * K;
+    float px = 0.0f, pw = 0.0f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = W[ou + k];
+        px += wv * (H[oi + k] - H[oj + k]);
+        pw += wv * wv;
+    }
+    const float x = wave_sum(px), w2 = wave_sum(pw);
+    const float sg = 1.0f / (1.0f + __expf(x));
+    if (lane == 0) {
+        atomicAdd(out, sg * (1.0f - sg) * w2);
+        atomicAdd(out + 1, 1.0f);
+    }
+}
+
+// scale[i] = (1 - a^N) / (N (1 - a)), a = (1 - rho)^(n_i / N): the sequentialisation factor of item i's summed deltas for this
+// step (build_step_counts), rho = rho_fixed + lr_data * (curv[0] / curv[1]) -- the measured data term, job-wide (curv = the two
+// floats at the tail of the reduced message; curv == nullptr or lr_data == 0: rho_fixed alone).
+__global__ void delta_scale_kernel(const float *__restrict__ counts, int I, int world, float rho_fixed, float lr_data,
+                                   const float *__restrict__ curv, float *__restrict__ scale) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= I) return;
+    float rho = rho_fixed;
+    if (curv && lr_data > 0.0f && curv[1] > 0.5f) rho += lr_data * curv[0] / curv[1];
+    rho = fminf(rho, 0.5f);
+    const float lb = log1pf(-rho);
+    const float a = __expf(lb * counts[i] / (float)world);
+    const float aN = __expf(lb * counts[i]);
+    scale[i] = a < 1.0f - 1e-6f ? (1.0f - aN) / ((float)world * (1.0f - a)) : 1.0f;
+}
+
+// scale[row]: the sequentialisation factor of that item for this step (delta_scale_kernel)
 // overlapped exchange: `base` is the state every rank agrees on bit for bit (all damped sums applied so far); the
 // live table is base + this rank's delta of the step whose exchange is still in flight.  When the sum of the
 // previous step arrives: base += s * sum, H = base + (delta of the step just computed), reference point = H.
@@ -777,8 +825,10 @@ struct cymf_bpr {
     std::vector<int64_t> user_bounds;   // [world + 1] user ranges of the ranks: download() gathers the W rows (optional)
     int exch_parity = 0;
     int64_t exch_count = 0;
-    const float *exch_scale = nullptr;
-    DevBuf<float> d_delta_scale;        // [steps_per_epoch][I] sequentialisation factors of the summed deltas
+    int32_t exch_step = 0;              // step whose exchange is in flight (its touch counts size the factors)
+    DevBuf<float> d_step_counts;        // [steps_per_epoch][I] job-wide touches of every item per step (build_step_counts)
+    DevBuf<float> d_delta_scale;        // [I] sequentialisation factors of the summed deltas of the step being applied
+    double rho_fixed = 0.0, rho_lr_data = 0.0;   // per-touch contraction: fixed part, and the learning rate of the measured data term
 
     // profiling of the dominant kernel
     bool profiling = false;
@@ -931,8 +981,10 @@ int finish_exchange(cymf_bpr *h, bool snapshot_if_idle, const float *local_cur =
     if (h->exch_pending) {
         const int pb = h->exch_parity;
         CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_reduced[pb], 0));
+        hipLaunchKernelGGL(delta_scale_kernel, dim3((h->I + 255) / 256), dim3(256), 0, h->stream, h->d_step_counts.p + (size_t)h->exch_step * h->I,
+                           h->I, comm_world(h->comm), (float)h->rho_fixed, (float)h->rho_lr_data, h->d_glob[pb].p + n, h->d_delta_scale.p);
         hipLaunchKernelGGL(correct_delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_base.p,
-                           h->d_glob[pb].p, local_cur, h->exch_scale, h->K, n);
+                           h->d_glob[pb].p, local_cur, h->d_delta_scale.p, h->K, n);
         CYMF_HIP(hipGetLastError());
         h->exch_pending = false;
     } else if (snapshot_if_idle) {
@@ -1279,6 +1331,17 @@ int run_one_step(cymf_bpr *h, int32_t fuse = 1) {
         }
         h->slots_done += e - b;
     } else if (e > b) {
+        if (h->comm) {   // the measured data term of this step's factors: two floats at the tail of the message that leaves after the step
+            const int64_t n = (int64_t)h->I * h->K;
+            float *tail = (h->overlap_exchange ? h->d_local[(int)(h->exch_count & 1)].p : h->d_delta.p) + n;
+            CYMF_HIP(hipMemsetAsync(tail, 0, DELTA_TAIL * sizeof(float), h->stream));
+            if (h->rho_lr_data > 0.0) {
+                const int64_t n_samples = std::min<int64_t>(e - b, 8192);
+                hipLaunchKernelGGL(bpr_curvature_kernel, dim3((unsigned)((n_samples + 3) / 4)), dim3(256), 0, h->stream, h->f32.W.p, h->f32.H.p, h->K,
+                                   h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, n_samples, tail);
+                CYMF_HIP(hipGetLastError());
+            }
+        }
         const int64_t chunks = (e - b + 63) / 64;
         // Number of wavefronts = bounded staleness (see the kernel header): at most `max_waves` from
         // the hardware side, and few enough that the rows in flight (waves * PF) stay a small
@@ -1350,19 +1413,21 @@ int run_one_step(cymf_bpr *h, int32_t fuse = 1) {
         CYMF_TRY(finish_exchange(h, /*snapshot_if_idle=*/true, h->d_local[b].p));
         CYMF_HIP(hipEventRecord(h->ev_delta_ready, h->stream));
         CYMF_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_delta_ready, 0));
-        CYMF_TRY(comm_allreduce_sum_f32_to(h->comm, h->d_local[b].p, h->d_glob[b].p, n, (int64_t)std::min(h->d_local[b].n, h->d_glob[b].n), h->comm_stream));
+        CYMF_TRY(comm_allreduce_sum_f32_to(h->comm, h->d_local[b].p, h->d_glob[b].p, n + DELTA_TAIL, (int64_t)std::min(h->d_local[b].n, h->d_glob[b].n), h->comm_stream));
         CYMF_HIP(hipEventRecord(h->ev_reduced[b], h->comm_stream));
         h->exch_pending = true;
         h->exch_parity = b;
-        h->exch_scale = h->d_delta_scale.p + (size_t)s * h->I;
+        h->exch_step = s;
         h->exch_count++;
     } else if (h->comm) {   // sum of the ranks' item-factor deltas
         const int64_t n = (int64_t)h->I * h->K;
         hipLaunchKernelGGL(delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_delta.p, n);
         CYMF_HIP(hipGetLastError());
-        CYMF_TRY(comm_allreduce_sum_f32(h->comm, h->d_delta.p, n, h->stream));
+        CYMF_TRY(comm_allreduce_sum_f32(h->comm, h->d_delta.p, n + DELTA_TAIL, h->stream));
+        hipLaunchKernelGGL(delta_scale_kernel, dim3((h->I + 255) / 256), dim3(256), 0, h->stream, h->d_step_counts.p + (size_t)s * h->I, h->I,
+                           comm_world(h->comm), (float)h->rho_fixed, (float)h->rho_lr_data, h->d_delta.p + n, h->d_delta_scale.p);
         hipLaunchKernelGGL(apply_delta_kernel, dim3(ew_blocks(n)), dim3(256), 0, h->stream, h->f32.H.p, h->d_snap.p, h->d_delta.p,
-                           h->d_delta_scale.p + (size_t)s * h->I, h->K, n);
+                           h->d_delta_scale.p, h->K, n);
         CYMF_HIP(hipGetLastError());
     }
     h->step_cursor += fuse;
@@ -1403,9 +1468,8 @@ int collect_skips(cymf_bpr *h) {   // after a stream sync: performed comes from 
 // n_i = positives of item i in the step over all ranks (all-reduced once here) + its expected share
 // of the uniform negatives; wd' = 2 wd leaves room for the curvature of the data term.  The optimizer state
 // (AdaGrad accumulators, Adam moments) of the item rows stays private to the rank, like W: only H is exchanged.
-int build_delta_scales(cymf_bpr *h, const std::vector<int32_t> &slot_item) {
+int build_step_counts(cymf_bpr *h, const std::vector<int32_t> &slot_item) {
     const int32_t S = h->steps_per_epoch;
-    const int world = comm_world(h->comm);
     std::vector<float> cnt((size_t)S * h->I, 0.0f);
     for (int32_t s = 0; s < S; ++s)
         for (int64_t t = h->step_off[s]; t < h->step_off[s + 1]; ++t) cnt[(size_t)s * h->I + slot_item[(size_t)t]] += 1.0f;
@@ -1423,23 +1487,23 @@ int build_delta_scales(cymf_bpr *h, const std::vector<int32_t> &slot_item) {
         CYMF_HIP(hipMemcpyAsync(slots.data(), d2.p, slots.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         CYMF_HIP(hipStreamSynchronize(h->stream));
     }
-    // per-touch contraction of a replica towards its local equilibrium, by optimizer.  SGD / AdaGrad: the weight decay
-    // contracts by lr*wd per touch and the data term (curvature sigma' w w^T along the user rows an item meets) by a
-    // multiple of lr that grows with the factor norms; measured with eight ranks on one GPU (tools/multirank_check.py,
-    // C3-shaped, lr 0.05, wd 0.01): rho = 0.001 (weight decay alone) lets the loss turn upwards after four epochs,
-    // 0.005 .. 0.1 track the single-rank run, 0.02 fits best -> 2 lr wd + 0.2 lr.  Adam moves every element by about lr per
-    // touch whatever the gradient: 5 lr (CPU emulation, tests/test_dist_gloo.py).
-    double rho = 2.0 * h->lr * h->wd + 0.2 * h->lr;
-    if (h->opt == CYMF_OPT_ADAM) rho = 5.0 * h->lr;
-    if (const char *er = getenv("CYMF_BPR_DELTA_RHO")) rho = atof(er);   // experiments (tools/multirank_check.py)
-    const double base = 1.0 - std::min(0.5, rho);
+    // n_i = positives of item i in the step over all ranks + its expected share of the step's uniform negatives
     for (int32_t s = 0; s < S; ++s)
-        for (int32_t i = 0; i < h->I; ++i) {
-            const double n_i = (double)cnt[(size_t)s * h->I + i] + (double)slots[s] / (double)h->I;
-            const double a = std::pow(base, n_i / world);
-            cnt[(size_t)s * h->I + i] = (float)(a < 1.0 - 1e-12 ? (1.0 - std::pow(a, world)) / (world * (1.0 - a)) : 1.0);
-        }
-    CYMF_TRY(h->d_delta_scale.upload(cnt.data(), cnt.size(), h->stream));
+        for (int32_t i = 0; i < h->I; ++i) cnt[(size_t)s * h->I + i] += slots[s] / (float)h->I;
+    CYMF_TRY(h->d_step_counts.upload(cnt.data(), cnt.size(), h->stream));
+    CYMF_TRY(h->d_delta_scale.alloc((size_t)h->I));
+    // Per-touch contraction rho of a replica towards its local equilibrium.  SGD / AdaGrad: the weight decay contracts by lr wd per
+    // touch (x2: head-room), the data term by lr sigma'(x) |w|^2 along the user row it meets -- MEASURED at the start of every step
+    // (bpr_curvature_kernel) and summed over the ranks with the deltas.  Round 2 used the constant lr / 5 fitted on one
+    // 200k x 20k problem: with the tiny initial factors (|w|^2 ~ 1e-5) nothing contracts, and damping the first steps' sums as
+    // if it did is what left eight ranks 24 % behind after the first epoch at C3's full size; as the factors grow the measured
+    // term takes over (C3 after three epochs: ~0.3 lr).  Adam moves every element by about lr per touch whatever the gradient:
+    // 5 lr (CPU emulation, tests/test_dist_gloo.py), no data term.  CYMF_BPR_DELTA_RHO fixes rho (experiments).
+    h->rho_fixed = 2.0 * h->lr * h->wd;
+    h->rho_lr_data = h->lr;
+    if (h->opt == CYMF_OPT_ADAM) { h->rho_fixed = 5.0 * h->lr; h->rho_lr_data = 0.0; }
+    if (const char *er = getenv("CYMF_BPR_DELTA_RHO")) { h->rho_fixed = atof(er); h->rho_lr_data = 0.0; }
+    if (const char *ed = getenv("CYMF_BPR_DELTA_DATA")) h->rho_lr_data = h->lr * atof(ed);   // multiple of the measured term (experiments)
     CYMF_HIP(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -1514,7 +1578,7 @@ int build_throughput_layout(cymf_bpr *h) {
     CYMF_TRY(h->d_slot_user.upload(su.data(), su.size(), h->stream));
     CYMF_TRY(h->d_slot_item.upload(si.data(), si.size(), h->stream));
     if (h->item_aligned && h->opt != CYMF_OPT_SGD) h->h_slot_item = si;
-    if (h->comm) CYMF_TRY(build_delta_scales(h, si));
+    if (h->comm) CYMF_TRY(build_step_counts(h, si));
     h->wave_ranges_for = -1;
     CYMF_TRY(h->d_slot_pos.upload(sp.data(), sp.size(), h->stream));
     CYMF_TRY(h->d_slot_local.upload(sl.data(), sl.size(), h->stream));
@@ -1724,7 +1788,7 @@ extern "C" int cymf_bpr_upload(cymf_bpr *h, const double *W, const double *H) {
         CYMF_TRY(h->d_snap.alloc(n));
         if (h->overlap_exchange) {
             // padded to a multiple of the world, padding zero: what the reduce-scatter + all-gather form of the exchange (CYMF_COMM_RS_AG=1) needs
-            const size_t n_pad = (size_t)comm_padded_count(h->comm, (int64_t)n);
+            const size_t n_pad = (size_t)comm_padded_count(h->comm, (int64_t)n + DELTA_TAIL);
             for (int b = 0; b < 2; ++b) {
                 CYMF_TRY(h->d_local[b].alloc(n_pad)); CYMF_TRY(h->d_glob[b].alloc(n_pad));
                 CYMF_TRY(h->d_local[b].zero(h->stream)); CYMF_TRY(h->d_glob[b].zero(h->stream));
@@ -1733,7 +1797,7 @@ extern "C" int cymf_bpr_upload(cymf_bpr *h, const double *W, const double *H) {
             CYMF_HIP(hipMemcpyAsync(h->d_base.p, h->f32.H.p, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
             h->exch_pending = false;
         } else {
-            CYMF_TRY(h->d_delta.alloc(n));
+            CYMF_TRY(h->d_delta.alloc(n + DELTA_TAIL));
         }
         CYMF_HIP(hipMemcpyAsync(h->d_snap.p, h->f32.H.p, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         CYMF_HIP(hipStreamSynchronize(h->stream));

@@ -754,7 +754,7 @@ void launch_relmf_step(int K, int opt, const RelStepDev &d, const int64_t *off, 
 // every rank forms the deltas of its replica against the last synchronised state -- context rows, their AdaGrad
 // accumulators, {context bias, its accumulator} -- in one buffer that is all-reduced; the accumulators are plain sums
 // of g^2, so their summed deltas ARE the sequential accumulators; rows and biases get the sequentialisation factor
-// of the item-delta exchange of bpr.hip (build_delta_scales there; rho = lr/5 per touch: AdaGrad, no weight decay).
+// of the item-delta exchange of bpr.hip (build_step_counts / delta_scale_kernel there; rho = lr/5 per touch: AdaGrad, no weight decay).
 __global__ void glove_delta_kernel(const float *__restrict__ H, const float *__restrict__ aH, const float2 *__restrict__ b2,
                                    const float *__restrict__ sH, const float *__restrict__ sA, const float2 *__restrict__ sB,
                                    float *__restrict__ D, int64_t VK, int64_t V) {
@@ -1419,7 +1419,7 @@ extern "C" int cymf_glove_set_data(cymf_glove *h, const int32_t *central, const 
         const double f_cold = (double)std::min<int64_t>(HOT, N) / (double)N;
         h->step_waves = std::max<int64_t>(1, std::min<int64_t>((int64_t)(2.0 / (f_cold * 8)), 256 * 8));
     }
-    if (h->comm) {   // sequentialisation factors per step and context word (see build_delta_scales in bpr.hip)
+    if (h->comm) {   // sequentialisation factors per step and context word (see build_step_counts in bpr.hip)
         const int world = comm_world(h->comm);
         std::vector<float> cntx((size_t)S * h->V, 0.0f);
         for (int32_t q = 0; q < S; ++q)

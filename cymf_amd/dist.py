@@ -65,18 +65,20 @@ def word_bounds(central, n_words, world):
     return np.concatenate([[0], np.minimum(bounds, n_words), [n_words]]).astype(np.int64)
 
 
-def delta_rho(optimizer, lr, wd):
-    """Per-touch contraction assumed for a replica of an item row (host mirror of build_delta_scales, csrc/bpr.hip)."""
-    rho = 2.0 * lr * wd + 0.2 * lr
+def delta_rho(optimizer, lr, wd, curvature=None):
+    """Per-touch contraction assumed for a replica of an item row (host mirror of build_step_counts / delta_scale_kernel,
+    csrc/bpr.hip).  curvature = the job-wide mean of sigma'(x) |w|^2 over a step's triplets, which the device measures at
+    the start of every step (bpr_curvature_kernel); None = round 2's constant stand-in lr / 5 (the CPU emulations)."""
+    rho = 2.0 * lr * wd + (0.2 * lr if curvature is None else lr * curvature)
     if optimizer == "adam":
         rho = 5.0 * lr
     return min(0.5, rho)
 
 
-def delta_scale(n_i, world, lr, wd, optimizer="sgd"):
-    """Sequentialisation factor of the summed item-factor deltas (host mirror of build_delta_scales in
+def delta_scale(n_i, world, lr, wd, optimizer="sgd", curvature=None):
+    """Sequentialisation factor of the summed item-factor deltas (host mirror of delta_scale_kernel in
     csrc/bpr.hip): n_i = updates of the item in the step over all ranks."""
-    base = 1.0 - delta_rho(optimizer, lr, wd)
+    base = 1.0 - delta_rho(optimizer, lr, wd, curvature)
     a = base ** (np.asarray(n_i, dtype=np.float64) / world)
     small = a >= 1.0 - 1e-12
     return np.where(small, 1.0, (1.0 - a ** world) / (world * np.where(small, 1.0, 1.0 - a)))

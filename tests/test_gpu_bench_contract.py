@@ -39,6 +39,11 @@ def test_bench_line_contract():
     assert set(sec) == {"C3_bpr_adam_k128", "C2_bpr_k64", "C2_bpr_adam_k64", "C4_wmf_k64", "C5_glove_k100", "relmf_20000x8000_k64"}
     assert "adam" in sec["C3_bpr_adam_k128"]["workload"] and "adam" in sec["C2_bpr_adam_k64"]["workload"]     # the reference's default optimizer (cymf/bpr.pyx:50)
     assert sec["C2_bpr_k64"]["steps_per_epoch"] >= 16
+    # every roofline names where its HBM traffic figure comes from (profiles/traffic.json, static); at --scale != 1 the
+    # full-size figures do not apply and the field is null for the size-dependent ones
+    for name, e in sec.items():
+        assert "traffic" in e["roofline"], name
+    assert "wmf_row_reg_kernel" in sec["C4_wmf_k64"]["roofline"]["kernel"] and "wmf_row_blk_kernel" in sec["C4_wmf_k64"]["k128"]["roofline"]["kernel"]
     for name, e in sec.items():
         assert "error" not in e, (name, e)
         assert e["value"] > 0 and e["ms"] > 0 and e["unit"] and e["workload"]
