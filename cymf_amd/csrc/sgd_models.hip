@@ -56,50 +56,132 @@ struct RelDev {
 
 // One draw: cell index -> (u, i) = (cell / I, cell % I)  (relmf.pyx:144-146)
 // CellT = uint32_t while U*I < 2^32 (one word of the index stream per draw), uint64_t beyond (64-bit draws, rng.hip)
+template <typename T, int R, bool PACKED, int OPT, bool HOG>
+__device__ __forceinline__ double relmf_sample(const RelDev<T> &d, int64_t u, int64_t i, int lane) {
+    constexpr int NS = opt_num_states(OPT);
+    const int K = d.K;
+    const T r = d.X[u * d.I + i], p = d.prop[i];
+    const int64_t ou = u * K, oi = i * K;
+    Row<T, R, PACKED> w, h, sw[NS ? NS : 1], sh[NS ? NS : 1];
+    w.load(d.W + ou, K, lane);
+    h.load(d.H + oi, K, lane);
+    if constexpr (NS >= 1) { sw[0].load(d.W0 + ou, K, lane); sh[0].load(d.H0 + oi, K, lane); }
+    if constexpr (NS >= 2) { sw[1].load(d.W1 + ou, K, lane); sh[1].load(d.H1 + oi, K, lane); }
+    T py = 0, pl = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        py += w.v[q] * h.v[q];
+        pl += w.v[q] * w.v[q] + h.v[q] * h.v[q];
+    }
+    const T y = wave_sum(py), l2 = wave_sum(pl);
+    const T qq = r / (p >= d.clip ? p : d.clip);                                  // r / dmax(p, M)
+    const double loss = (double)(qq * (1 - y) * (1 - y) + (1 - qq) * y * y + d.wd * l2);  // model.pyx:117
+    const T c = qq * (1 - y) + (1 - qq) * (0 - y);                                // model.pyx:131-139 (no factor 2)
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const T wv = w.v[q], hv = h.v[q];
+        const T gw = -(c * hv) + d.wd * wv;
+        const T gh = -(c * wv) + d.wd * hv;
+        T dummy = 0;
+        opt_update<T, OPT, HOG>(d.opt, w.v[q], OPT >= 1 ? sw[0].v[q] : dummy, OPT == 2 ? sw[1].v[q] : dummy, gw);
+        opt_update<T, OPT, HOG>(d.opt, h.v[q], OPT >= 1 ? sh[0].v[q] : dummy, OPT == 2 ? sh[1].v[q] : dummy, gh);
+    }
+    w.store(d.W + ou, K, lane);
+    h.store(d.H + oi, K, lane);
+    if constexpr (NS >= 1) { sw[0].store(d.W0 + ou, K, lane); sh[0].store(d.H0 + oi, K, lane); }
+    if constexpr (NS >= 2) { sw[1].store(d.W1 + ou, K, lane); sh[1].store(d.H1 + oi, K, lane); }
+    return loss;
+}
+
 template <typename T, int R, bool PACKED, int OPT, bool HOG, typename CellT>
 __global__ __launch_bounds__(256) void relmf_kernel(RelDev<T> d, const CellT *__restrict__ cells, int64_t n,
                                                    double *__restrict__ loss_acc) {
     const int lane = lane_id();
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    constexpr int NS = opt_num_states(OPT);
-    const int K = d.K;
     double loss_sum = 0.0;
     for (int64_t s = wave0; s < n; s += n_waves) {
         const CellT cell = cells[s];
-        const int64_t u = (int64_t)(cell / (CellT)d.I), i = (int64_t)(cell % (CellT)d.I);
-        const T r = d.X[u * d.I + i], p = d.prop[i];
-        const int64_t ou = u * K, oi = i * K;
-        Row<T, R, PACKED> w, h, sw[NS ? NS : 1], sh[NS ? NS : 1];
-        w.load(d.W + ou, K, lane);
-        h.load(d.H + oi, K, lane);
-        if constexpr (NS >= 1) { sw[0].load(d.W0 + ou, K, lane); sh[0].load(d.H0 + oi, K, lane); }
-        if constexpr (NS >= 2) { sw[1].load(d.W1 + ou, K, lane); sh[1].load(d.H1 + oi, K, lane); }
-        T py = 0, pl = 0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            py += w.v[q] * h.v[q];
-            pl += w.v[q] * w.v[q] + h.v[q] * h.v[q];
-        }
-        const T y = wave_sum(py), l2 = wave_sum(pl);
-        const T qq = r / (p >= d.clip ? p : d.clip);                                  // r / dmax(p, M)
-        loss_sum += (double)(qq * (1 - y) * (1 - y) + (1 - qq) * y * y + d.wd * l2);  // model.pyx:117
-        const T c = qq * (1 - y) + (1 - qq) * (0 - y);                                // model.pyx:131-139 (no factor 2)
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const T wv = w.v[q], hv = h.v[q];
-            const T gw = -(c * hv) + d.wd * wv;
-            const T gh = -(c * wv) + d.wd * hv;
-            T dummy = 0;
-            opt_update<T, OPT, HOG>(d.opt, w.v[q], OPT >= 1 ? sw[0].v[q] : dummy, OPT == 2 ? sw[1].v[q] : dummy, gw);
-            opt_update<T, OPT, HOG>(d.opt, h.v[q], OPT >= 1 ? sh[0].v[q] : dummy, OPT == 2 ? sh[1].v[q] : dummy, gh);
-        }
-        w.store(d.W + ou, K, lane);
-        h.store(d.H + oi, K, lane);
-        if constexpr (NS >= 1) { sw[0].store(d.W0 + ou, K, lane); sh[0].store(d.H0 + oi, K, lane); }
-        if constexpr (NS >= 2) { sw[1].store(d.W1 + ou, K, lane); sh[1].store(d.H1 + oi, K, lane); }
+        loss_sum += relmf_sample<T, R, PACKED, OPT, HOG>(d, (int64_t)(cell / (CellT)d.I), (int64_t)(cell % (CellT)d.I), lane);
     }
     if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
+}
+
+// ------------------------------------------------------------------ EXACT: dataflow execution of the sequential order
+// The two-row form of bpr_ticket_kernel (bpr.hip).  Sample s touches row a of table A and row b of table B; it
+// may run as soon as the earlier samples touching those rows are done.  The host numbers the accesses of every row in
+// sequential order (sample s is access ka[s] of its A row, kb[s] of its B row); a wavefront takes the next sample of the order
+// from a dispenser, waits until the two per-row counters show its turn numbers, loads the rows behind an agent-scope acquire
+// fence, updates and stores them, and bumps the counters behind a release fence.  Samples are handed out in order to whichever
+// wavefront asks next, so the smallest unfinished sample is always held by a RUNNING wavefront: no deadlock whatever part of the
+// grid is resident; a spin limit turns a broken schedule into an error instead of a hang.  Replaces one launch per level
+// (RelMF 30 x 40: 40 launches per epoch; GloVe on 120 words: ~300): the same arithmetic in the same order, bit for bit.
+constexpr unsigned int TICKET2_SPIN_LIMIT = 1u << 20;
+
+__device__ __forceinline__ bool ticket_wait2(const unsigned int *c0, unsigned int t0, const unsigned int *c1, unsigned int t1) {
+    unsigned int spins = 0;
+    while (true) {
+        const unsigned int v0 = __hip_atomic_load(c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int v1 = __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v0 == t0 && v1 == t1) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > TICKET2_SPIN_LIMIT) return false;
+    }
+}
+
+// Body: double operator()(int64_t s, int lane, int64_t &a, int64_t &b) -- reports the sample's rows, then (after the wait)
+// run(s, lane) does the loads, the update and the stores
+template <typename Sample>
+__device__ __forceinline__ void ticket2_loop(Sample smp, int64_t n, const uint32_t *__restrict__ ka, const uint32_t *__restrict__ kb,
+                                             unsigned int *doneA, unsigned int *doneB, unsigned long long *next,
+                                             double *__restrict__ loss_acc, int *err) {
+    const int lane = lane_id();
+    double loss_sum = 0.0;
+    auto grab = [&]() -> int64_t {
+        unsigned long long v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(next, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
+    int64_t s = grab();
+    while (s < n) {
+        const int64_t s_next = grab();   // asked for early: its latency hides behind this sample's wait and loads
+        int64_t a, b;
+        smp.rows(s, a, b);
+        if (!ticket_wait2(doneA + a, ka[s], doneB + b, kb[s])) {   // cannot happen with a consistent schedule; never hang the device on a bad one
+            if (lane == 0) atomicExch(err, 1);
+            break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        loss_sum += smp.run(s, a, b, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every lane's stores are complete before lane 0 publishes the turns
+        if (lane == 0) {
+            __hip_atomic_fetch_add(doneA + a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(doneB + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s = s_next;
+    }
+    if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
+}
+
+template <typename T, int R, bool PACKED, int OPT>
+struct RelmfTicketSample {
+    RelDev<T> d;
+    const uint32_t *cells;
+    __device__ __forceinline__ void rows(int64_t s, int64_t &u, int64_t &i) const {
+        const uint32_t cell = cells[s];
+        u = (int64_t)(cell / (uint32_t)d.I);
+        i = (int64_t)(cell % (uint32_t)d.I);
+    }
+    __device__ __forceinline__ double run(int64_t, int64_t u, int64_t i, int lane) const { return relmf_sample<T, R, PACKED, OPT, false>(d, u, i, lane); }
+};
+
+template <typename T, int R, bool PACKED, int OPT>
+__global__ __launch_bounds__(256) void relmf_ticket_kernel(RelDev<T> d, const uint32_t *__restrict__ cells, int64_t n,
+                                                          const uint32_t *__restrict__ ku, const uint32_t *__restrict__ ki,
+                                                          unsigned int *doneW, unsigned int *doneH, unsigned long long *next,
+                                                          double *__restrict__ loss_acc, int *err) {
+    ticket2_loop(RelmfTicketSample<T, R, PACKED, OPT>{d, cells}, n, ku, ki, doneW, doneH, next, loss_acc, err);
 }
 
 // any K (cymf/relmf.pyx:42 takes any num_components): rows wider than the register layouts (K > 256) are streamed from
@@ -160,6 +242,58 @@ __device__ __forceinline__ float flog(float a) { return logf(a); }
 __device__ __forceinline__ double flog(double a) { return log(a); }
 
 template <typename T, int R, bool PACKED>
+__device__ __forceinline__ double glove_sample(const GloveDev<T> &d, int64_t c, int64_t x, T cnt, int lane) {
+    const int K = d.K;
+    const int64_t oc = c * K, ox = x * K;
+    Row<T, R, PACKED> w, h, aw, ah;
+    w.load(d.W + oc, K, lane);
+    h.load(d.H + ox, K, lane);
+    aw.load(d.aW + oc, K, lane);
+    ah.load(d.aH + ox, K, lane);
+    T bw = d.bW[c], bh = d.bH[x], abw = d.abW[c], abh = d.abH[x];
+    T pd = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) pd += w.v[q] * h.v[q];
+    T diff = wave_sum(pd);                                      // model.pyx:174-175
+    diff += bw + bh;                                            // :176
+    diff -= flog(cnt);                                          // :177
+    const T tmp = diff;
+    const T f = fpow(cnt / d.x_max, d.alpha);
+    diff *= f < (T)1 ? f : (T)1;                                // :179, weight_func :34-35
+    const double loss = (double)((T)0.5 * diff * tmp);          // :180
+    const T g2 = diff * diff;
+    // biases: AdaGrad-updated K times per sample (model.pyx:195-204):
+    //   acc_k = acc_0 + k g^2,  b_K = b_0 - lr g sum_{k=1..K} 1/sqrt(acc_k); lanes share the k's
+    T pbw = 0, pbh = 0;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int k = Row<T, R, PACKED>::kof(lane, q);
+        if (k < K) {
+            pbw += (T)1 / fsqrt(abw + (T)(k + 1) * g2);
+            pbh += (T)1 / fsqrt(abh + (T)(k + 1) * g2);
+        }
+        const T wv = w.v[q], hv = h.v[q];
+        const T gw = diff * hv, gh = diff * wv;
+        aw.v[q] += gw * gw;
+        w.v[q] -= d.lr * gw / fsqrt(aw.v[q]);
+        ah.v[q] += gh * gh;
+        h.v[q] -= d.lr * gh / fsqrt(ah.v[q]);
+    }
+    const T sbw = wave_sum(pbw), sbh = wave_sum(pbh);
+    w.store(d.W + oc, K, lane);
+    h.store(d.H + ox, K, lane);
+    aw.store(d.aW + oc, K, lane);
+    ah.store(d.aH + ox, K, lane);
+    if (lane == 0) {
+        d.bW[c] = bw - d.lr * diff * sbw;
+        d.bH[x] = bh - d.lr * diff * sbh;
+        d.abW[c] = abw + (T)K * g2;
+        d.abH[x] = abh + (T)K * g2;
+    }
+    return loss;
+}
+
+template <typename T, int R, bool PACKED>
 __global__ __launch_bounds__(256) void glove_kernel(GloveDev<T> d, const int32_t *__restrict__ central,
                                                    const int32_t *__restrict__ context,
                                                    const T *__restrict__ counts, int64_t n,
@@ -167,59 +301,28 @@ __global__ __launch_bounds__(256) void glove_kernel(GloveDev<T> d, const int32_t
     const int lane = lane_id();
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int K = d.K;
     double loss_sum = 0.0;
-    for (int64_t s = wave0; s < n; s += n_waves) {
-        const int64_t c = central[s], x = context[s];
-        const T cnt = counts[s];
-        const int64_t oc = c * K, ox = x * K;
-        Row<T, R, PACKED> w, h, aw, ah;
-        w.load(d.W + oc, K, lane);
-        h.load(d.H + ox, K, lane);
-        aw.load(d.aW + oc, K, lane);
-        ah.load(d.aH + ox, K, lane);
-        T bw = d.bW[c], bh = d.bH[x], abw = d.abW[c], abh = d.abH[x];
-        T pd = 0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) pd += w.v[q] * h.v[q];
-        T diff = wave_sum(pd);                                      // model.pyx:174-175
-        diff += bw + bh;                                            // :176
-        diff -= flog(cnt);                                          // :177
-        const T tmp = diff;
-        const T f = fpow(cnt / d.x_max, d.alpha);
-        diff *= f < (T)1 ? f : (T)1;                                // :179, weight_func :34-35
-        loss_sum += (double)((T)0.5 * diff * tmp);                  // :180
-        const T g2 = diff * diff;
-        // biases: AdaGrad-updated K times per sample (model.pyx:195-204):
-        //   acc_k = acc_0 + k g^2,  b_K = b_0 - lr g sum_{k=1..K} 1/sqrt(acc_k); lanes share the k's
-        T pbw = 0, pbh = 0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const int k = Row<T, R, PACKED>::kof(lane, q);
-            if (k < K) {
-                pbw += (T)1 / fsqrt(abw + (T)(k + 1) * g2);
-                pbh += (T)1 / fsqrt(abh + (T)(k + 1) * g2);
-            }
-            const T wv = w.v[q], hv = h.v[q];
-            const T gw = diff * hv, gh = diff * wv;
-            aw.v[q] += gw * gw;
-            w.v[q] -= d.lr * gw / fsqrt(aw.v[q]);
-            ah.v[q] += gh * gh;
-            h.v[q] -= d.lr * gh / fsqrt(ah.v[q]);
-        }
-        const T sbw = wave_sum(pbw), sbh = wave_sum(pbh);
-        w.store(d.W + oc, K, lane);
-        h.store(d.H + ox, K, lane);
-        aw.store(d.aW + oc, K, lane);
-        ah.store(d.aH + ox, K, lane);
-        if (lane == 0) {
-            d.bW[c] = bw - d.lr * diff * sbw;
-            d.bH[x] = bh - d.lr * diff * sbh;
-            d.abW[c] = abw + (T)K * g2;
-            d.abH[x] = abh + (T)K * g2;
-        }
-    }
+    for (int64_t s = wave0; s < n; s += n_waves) loss_sum += glove_sample<T, R, PACKED>(d, central[s], context[s], counts[s], lane);
     if (lane == 0 && loss_sum != 0.0) atomicAdd(loss_acc, loss_sum);
+}
+
+// EXACT: the pairs in their given order, executed as a dataflow (ticket2_loop above); a word's bias and accumulator travel with
+// its row (central word: bW, abW; context word: bH, abH), so the two row counters order them as well
+template <typename T, int R, bool PACKED>
+struct GloveTicketSample {
+    GloveDev<T> d;
+    const int32_t *central, *context;
+    const T *counts;
+    __device__ __forceinline__ void rows(int64_t s, int64_t &c, int64_t &x) const { c = central[s]; x = context[s]; }
+    __device__ __forceinline__ double run(int64_t s, int64_t c, int64_t x, int lane) const { return glove_sample<T, R, PACKED>(d, c, x, counts[s], lane); }
+};
+
+template <typename T, int R, bool PACKED>
+__global__ __launch_bounds__(256) void glove_ticket_kernel(GloveDev<T> d, const int32_t *__restrict__ central, const int32_t *__restrict__ context,
+                                                          const T *__restrict__ counts, int64_t n, const uint32_t *__restrict__ kc,
+                                                          const uint32_t *__restrict__ kx, unsigned int *doneC, unsigned int *doneX,
+                                                          unsigned long long *next, double *__restrict__ loss_acc, int *err) {
+    ticket2_loop(GloveTicketSample<T, R, PACKED>{d, central, context, counts}, n, kc, kx, doneC, doneX, next, loss_acc, err);
 }
 
 // any K (cymf/glove.pyx:57): the two-pass form of glove_kernel for rows wider than the register layouts (K > 256)
@@ -836,6 +939,72 @@ void launch_relmf(int K, int opt, const RelDev<T> &d, const CellT *cells, int64_
 #undef CALL_
 }
 
+// dataflow state of an exact-mode epoch: per-row counters of finished accesses (table A rows, then table B rows), the
+// dispenser and the error flag
+struct TicketState {
+    DevBuf<uint32_t> ka, kb, done;
+    DevBuf<unsigned long long> next;
+    DevBuf<int> err;
+    int n_cu = 0;
+    int prepare(int64_t nA, int64_t nB, int device, hipStream_t s) {
+        if (!n_cu) {
+            CYMF_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+            if (n_cu <= 0) n_cu = 256;
+        }
+        CYMF_TRY(done.alloc((size_t)(nA + nB)));
+        CYMF_TRY(next.alloc(1));
+        CYMF_TRY(err.alloc(1));
+        CYMF_TRY(done.zero(s));
+        CYMF_TRY(next.zero(s));
+        CYMF_TRY(err.zero(s));
+        return 0;
+    }
+    int blocks(int64_t n) const { return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)2 * n_cu, (n + 3) / 4)); }   // 8 waves per CU: a latency chain
+    int check(hipStream_t s, const char *who) {
+        int e = 0;
+        CYMF_HIP(hipMemcpyAsync(&e, err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        CYMF_HIP(hipStreamSynchronize(s));
+        if (e) return fail(CYMF_ERR_HIP, "%s: a sample waited beyond the spin limit for its turn (inconsistent schedule)", who);
+        return 0;
+    }
+};
+
+// turn numbers: sample s is access ka[s] of row a[s] and access kb[s] of row b[s] in sequential order
+template <typename IndexA, typename IndexB>
+void number_turns(int64_t n, IndexA a_of, IndexB b_of, int64_t nA, int64_t nB, std::vector<uint32_t> &ka, std::vector<uint32_t> &kb) {
+    std::vector<uint32_t> cA((size_t)nA, 0u), cB((size_t)nB, 0u);
+    ka.resize((size_t)n);
+    kb.resize((size_t)n);
+    for (int64_t s = 0; s < n; ++s) {
+        ka[(size_t)s] = cA[(size_t)a_of(s)]++;
+        kb[(size_t)s] = cB[(size_t)b_of(s)]++;
+    }
+}
+
+template <typename T>
+void launch_relmf_ticket(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, TicketState &t, int32_t U, double *loss, hipStream_t s) {
+#define OPT_(R_, P_, O_) hipLaunchKernelGGL((relmf_ticket_kernel<T, R_, P_, O_>), dim3(t.blocks(n)), dim3(256), 0, s, d, cells, n, t.ka.p, t.kb.p, \
+                                            t.done.p, t.done.p + U, t.next.p, loss, t.err.p)
+#define CALL_(R_, P_)                                                                              \
+    do {                                                                                           \
+        if (opt == CYMF_OPT_SGD) OPT_(R_, P_, CYMF_OPT_SGD);                                       \
+        else if (opt == CYMF_OPT_ADAGRAD) OPT_(R_, P_, CYMF_OPT_ADAGRAD);                          \
+        else OPT_(R_, P_, CYMF_OPT_ADAM);                                                          \
+    } while (0)
+    CYMF_DISPATCH_LAYOUT(K, CALL_);
+#undef CALL_
+#undef OPT_
+}
+
+template <typename T>
+void launch_glove_ticket(int K, const GloveDev<T> &d, const int32_t *c, const int32_t *x, const T *cnt, int64_t n, TicketState &t, int32_t V,
+                         double *loss, hipStream_t s) {
+#define CALL_(R_, P_) hipLaunchKernelGGL((glove_ticket_kernel<T, R_, P_>), dim3(t.blocks(n)), dim3(256), 0, s, d, c, x, cnt, n, t.ka.p, t.kb.p, \
+                                         t.done.p, t.done.p + V, t.next.p, loss, t.err.p)
+    CYMF_DISPATCH_LAYOUT(K, CALL_);
+#undef CALL_
+}
+
 template <typename T>
 void launch_glove(int K, const GloveDev<T> &d, const int32_t *c, const int32_t *x, const T *cnt, int64_t n,
                   double *loss, int grid, hipStream_t s) {
@@ -922,6 +1091,7 @@ struct cymf_relmf {
     DevBuf<double> d_loss;
     DevBuf<int> d_err;
     std::vector<uint32_t> h_cells;
+    TicketState ticket;                 // exact mode: dataflow execution (CYMF_RELMF_EXACT_LEVELS=1: one launch per level)
     bool have_data = false, have_params = false;
 };
 
@@ -1099,6 +1269,26 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
         h->h_cells.resize((size_t)N);
         CYMF_HIP(hipMemcpyAsync(h->h_cells.data(), h->d_cells.p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         CYMF_HIP(hipStreamSynchronize(h->stream));
+        const char *lv_env = getenv("CYMF_RELMF_EXACT_LEVELS");   // (read per epoch: the tests switch it inside one process)
+        const bool by_levels = lv_env && lv_env[0] == '1';
+        if (!by_levels && h->K <= 256 && !h->force_wide_cells) {
+            // the epoch's draws in their own order, as ONE dataflow launch (relmf_ticket_kernel): the host only numbers the accesses
+            std::vector<uint32_t> ku, ki;
+            const uint32_t I32 = (uint32_t)h->I;
+            number_turns(N, [&](int64_t s) { return h->h_cells[(size_t)s] / I32; }, [&](int64_t s) { return h->h_cells[(size_t)s] % I32; },
+                         h->U, h->I, ku, ki);
+            CYMF_TRY(h->ticket.prepare(h->U, h->I, h->device, h->stream));
+            CYMF_TRY(h->ticket.ka.upload(ku.data(), ku.size(), h->stream));
+            CYMF_TRY(h->ticket.kb.upload(ki.data(), ki.size(), h->stream));
+            launch_relmf_ticket<T>(h->K, h->opt, d, h->d_cells.p, N, h->ticket, h->U, h->d_loss.p, h->stream);
+            CYMF_HIP(hipGetLastError());
+            CYMF_TRY(h->ticket.check(h->stream, "relmf exact mode"));
+            double loss_t = 0;
+            CYMF_HIP(hipMemcpyAsync(&loss_t, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            CYMF_HIP(hipStreamSynchronize(h->stream));
+            if (loss_out) *loss_out = loss_t;
+            return 0;
+        }
         std::vector<int32_t> su((size_t)N), si((size_t)N);
         for (int64_t s = 0; s < N; ++s) {
             su[s] = (int32_t)(h->h_cells[s] / (uint32_t)h->I);
@@ -1297,8 +1487,10 @@ struct cymf_glove {
     GloveStore<float> f32;
     GloveStore<double> f64;
     int64_t N = 0;
-    DevBuf<int32_t> d_central, d_context;   // EXACT: level order; THROUGHPUT: given order
+    DevBuf<int32_t> d_central, d_context;   // EXACT by levels: level order; otherwise the given order
     std::vector<int64_t> level_off;
+    TicketState ticket;                     // exact mode: dataflow execution of the given order (CYMF_GLOVE_EXACT_LEVELS=1: by levels)
+    bool use_tickets = false;
     double f_max = 1.0;                     // share of the pairs that touch the most frequent word
     DevBuf<double> d_loss;
     // multi-GPU: central-word ranges per rank, steps (local windows of the pair order), exchange buffers
@@ -1375,10 +1567,20 @@ extern "C" int cymf_glove_set_data(cymf_glove *h, const int32_t *central, const 
     std::vector<int32_t> c(central, central + N), x(context, context + N);
     std::vector<double> cnt(counts, counts + N);
     h->level_off.clear();
+    h->use_tickets = false;
     if (h->mode == CYMF_MODE_EXACT && N > 0) {   // the order is fixed for all epochs: schedule once
-        std::vector<int64_t> order;
-        level_schedule(N, central, context, h->V, h->Vc, order, h->level_off);
-        for (int64_t p = 0; p < N; ++p) { c[p] = central[order[p]]; x[p] = context[order[p]]; cnt[p] = counts[order[p]]; }
+        const char *lv = getenv("CYMF_GLOVE_EXACT_LEVELS");
+        if (!(lv && lv[0] == '1') && h->K <= 256) {   // dataflow: the pairs stay in their given order, the accesses of every row are numbered
+            std::vector<uint32_t> kc, kx;
+            number_turns(N, [&](int64_t s) { return central[s]; }, [&](int64_t s) { return context[s]; }, h->V, h->Vc, kc, kx);
+            CYMF_TRY(h->ticket.ka.upload(kc.data(), kc.size(), h->stream));
+            CYMF_TRY(h->ticket.kb.upload(kx.data(), kx.size(), h->stream));
+            h->use_tickets = true;
+        } else {
+            std::vector<int64_t> order;
+            level_schedule(N, central, context, h->V, h->Vc, order, h->level_off);
+            for (int64_t p = 0; p < N; ++p) { c[p] = central[order[p]]; x[p] = context[order[p]]; cnt[p] = counts[order[p]]; }
+        }
     }
     const int32_t S = h->step_path ? std::max(1, h->steps_per_epoch) : 1;
     h->step_off.assign((size_t)S + 1, 0);
@@ -1557,6 +1759,11 @@ static int glove_epoch(cymf_glove *h, GloveStore<T> &st, double *loss_out) {
             }
         } else if (h->mode == CYMF_MODE_THROUGHPUT) {
             launch_glove<T>(h->K, d, h->d_central.p, h->d_context.p, st.counts.p, h->N, h->d_loss.p, hogwild_grid(h->N, h->f_max), h->stream);
+        } else if (h->use_tickets) {
+            CYMF_TRY(h->ticket.prepare(h->V, h->Vc, h->device, h->stream));
+            launch_glove_ticket<T>(h->K, d, h->d_central.p, h->d_context.p, st.counts.p, h->N, h->ticket, h->V, h->d_loss.p, h->stream);
+            CYMF_HIP(hipGetLastError());
+            CYMF_TRY(h->ticket.check(h->stream, "glove exact mode"));
         } else {
             for (size_t lv = 1; lv + 1 < h->level_off.size(); ++lv) {
                 const int64_t b = h->level_off[lv], n = h->level_off[lv + 1] - b;

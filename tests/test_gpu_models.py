@@ -31,6 +31,31 @@ def test_relmf_vs_reference_fixture(dtype):
             assert _close(m.H, g[f"H_{opt}_{ep}"], tol), (opt, ep)
 
 
+@pytest.mark.parametrize("opt", ["sgd", "adagrad", "adam"])
+def test_relmf_exact_mode_dataflow_and_level_launches_agree(opt, monkeypatch):
+    """Exact mode as ONE dataflow launch (relmf_ticket_kernel: per-row turn counters, ordered dispenser; the default) and as one
+    launch per level (CYMF_RELMF_EXACT_LEVELS=1) are two executions of the same sequential order: float64 factors bit-identical,
+    losses equal to the rounding of their sums; both equal to the oracle (cymf/relmf.pyx:142-148).  A 12-item catalogue: every
+    item row is a hot hand-off chain."""
+    rs = np.random.RandomState(4)
+    U, I, K = 200, 12, 24
+    X = (rs.rand(U, I) < 0.3).astype(np.float64)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CYMF_RELMF_EXACT_LEVELS", flag)
+        m = RelMF(K, 0.1, 0.02, opt, 0.01)
+        m.fit(X, num_epochs=3, num_threads=1, dtype="float64")
+        out.append((m.W.copy(), m.H.copy(), np.array(m.losses)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12)
+    W, H = oracle.reference_init(U, I, K)
+    prop = np.maximum(X.mean(axis=0) / X.mean(axis=0).max(), 1e-5) ** 0.5
+    om = oracle.RelMf(W, H, opt, 0.02, 0.01, 0.1)
+    for _ in range(3):
+        om.epoch(X, prop)
+    assert _close(out[0][0], W, 1e-10) and _close(out[0][1], H, 1e-10)
+
+
 def test_relmf_larger_vs_oracle_and_sparse_input():
     from scipy import sparse
     rs = np.random.RandomState(2)
@@ -152,6 +177,24 @@ def test_glove_vs_reference_fixture(K, dtype):
     m.fit(X, 2, 1, dtype=dtype)
     assert _close(m.W, g[f"W_k{K}"], TOL[dtype])
     assert _close(m.bias, g[f"bias_k{K}"], TOL[dtype])
+
+
+@pytest.mark.parametrize("K", [16, 100])
+def test_glove_exact_mode_dataflow_and_level_launches_agree(K, monkeypatch):
+    """GloVe's exact mode as one dataflow launch (glove_ticket_kernel; the default) and by levels (CYMF_GLOVE_EXACT_LEVELS=1):
+    float64 factors and biases bit-identical (cymf/glove.pyx:149-156; a word's bias travels with its row)."""
+    g = golden("glove_120")
+    X = csr_from_golden(g, data=g["data"])
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CYMF_GLOVE_EXACT_LEVELS", flag)
+        np.random.seed(int(g["np_seed"]))
+        m = GloVe(K, float(g["lr"]), float(g["alpha"]), float(g["x_max"]))
+        m.fit(X, 2, 1, dtype="float64")
+        out.append((m.W.copy(), m.bias.copy(), np.array(m.losses)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12)
+    assert _close(out[0][0], g[f"W_k{K}"], 1e-10) and _close(out[0][1], g[f"bias_k{K}"], 1e-10)
 
 
 def test_glove_text8_shaped_vs_oracle_and_hogwild():

@@ -41,6 +41,21 @@ def main():
     ev = Evaluator(d["Xte"], d["Xtr_head"])
     n = d["n_eval_users"]
     rows = []
+    # The epoch losses the trainers report are ONLINE means (every triplet against the factors as they stand when it is worked --
+    # for a rank: against its own replica of H, which within a step has seen only that rank's share of the updates).  The state
+    # of the MODEL is measured offline: the BPR loss of the downloaded factors on a fixed sample of 2 M training triplets with
+    # fixed uniform negatives (cymf/model.pyx:60's data term; the same sample for every run).
+    rs = np.random.RandomState(99)
+    pick = rs.randint(0, len(d["users"]), 2_000_000)
+    su, si, sj = d["users"][pick], d["pos"][pick], rs.randint(0, I, len(pick))
+
+    def offline_loss(W, H):
+        out = 0.0
+        for b in range(0, len(su), 250_000):
+            u, i, j = su[b:b + 250_000], si[b:b + 250_000], sj[b:b + 250_000]
+            x = np.einsum("nk,nk->n", W[u], H[i] - H[j])
+            out += np.logaddexp(0.0, -x).sum()
+        return float(out / len(su))
 
     one = BprTrainer(U, I, K, args.opt, args.lr, 0.01, mode="throughput", steps_per_epoch=25)
     one.set_data(d["users"], d["pos"], d["indptr"], d["cols"])
@@ -51,7 +66,8 @@ def main():
     one.close()
     r1 = ev.evaluate(W1[:n], H1)["Recall@5"]
     nH1 = float(np.linalg.norm(H1))
-    rows.append({"run": "single rank, 25 steps per epoch", "loss": [float(x) for x in loss1], "nH": nH1, "recall5": r1})
+    off1 = offline_loss(W1, H1)
+    rows.append({"run": "single rank, 25 steps per epoch", "loss": [float(x) for x in loss1], "offline_loss": off1, "nH": nH1, "recall5": r1})
     print(json.dumps(rows[-1]), flush=True)
     del W1
 
@@ -96,8 +112,9 @@ def main():
             H8 = res[0][2]
             W8 = np.concatenate([r[1] for r in res])
             r8 = ev.evaluate(W8[:n], H8)["Recall@5"]
+            off8 = offline_loss(W8, H8)
             rows.append({"run": f"{args.world} ranks, {S} steps per epoch, rho {rho}", "S": S, "rho": rho, "loss": [float(x) for x in job_loss],
-                         "loss_rel": [float(a / b - 1) for a, b in zip(job_loss, loss1)], "nH_rel": float(np.linalg.norm(H8) / nH1 - 1),
+                         "loss_rel": [float(a / b - 1) for a, b in zip(job_loss, loss1)], "offline_loss": off8, "offline_loss_rel": off8 / off1 - 1, "nH_rel": float(np.linalg.norm(H8) / nH1 - 1),
                          "recall5": r8, "recall5_diff": r8 - r1, "wall_s": time.time() - t0})
             print(json.dumps(rows[-1]), flush=True)
             del W8, H8, res
