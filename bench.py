@@ -183,7 +183,9 @@ def main():
     if pretend:
         world = pretend                                   # rank 0 of `pretend`; restored below for the report
     if world > 1:
-        comm = dist.Comm.local_group(1, I * K + 64, device=device)[0] if pretend else dist.Comm.from_env(device=device)
+        # (pretend: a real RCCL communicator of ONE rank -- its collectives are asynchronous copies in stream order, as the ranks'
+        # are; the in-process local group synchronises the host twice per collective and would charge that to the schedule)
+        comm = dist.Comm(0, 1, device, dist.Comm.unique_id()) if pretend else dist.Comm.from_env(device=device)
         lo, hi = dist.user_shards(indptr, world)[rank]
         all_users = data["users"]
         mine = np.nonzero((all_users >= lo) & (all_users < hi))[0]       # global positions of my triplets
@@ -193,7 +195,11 @@ def main():
     else:
         users, positives, gpos = data["users"], data["positives"], None
         csr_indptr, csr_indices = indptr.astype(np.int32), cols
-    spe = nearest_divisor(args.steps, nnz / (args.batch * world))
+    # steps per epoch: windows of ~`batch` triplets per GPU -- but about 6 per epoch at least once the job is sharded: a step ends
+    # with the exchange of the item deltas, and a job of eight ranks that meets only 3 times per epoch is still 9 % behind the
+    # single rank in model loss after three epochs, at 6 within 2 % (profiles/r03_c3_eight_ranks.md)
+    ideal = nnz / (args.batch * world)
+    spe = nearest_divisor(args.steps, ideal if world == 1 else max(ideal, 6.0))
     epochs_covered = args.steps // spe
     log(rank, f"rank {rank}/{world}: {len(users)} local triplets, {spe} steps/epoch (~{nnz // (spe * world)} triplets/GPU/step), "
               f"timed window = {epochs_covered} epoch(s)")

@@ -588,24 +588,34 @@ __global__ __launch_bounds__(256) void bpr_curvature_kernel(const float *__restr
                                                            const int32_t *__restrict__ slot_user, const int32_t *__restrict__ slot_item,
                                                            const int32_t *__restrict__ slot_neg, int64_t b, int64_t e, int64_t n_samples,
                                                            float *__restrict__ out) {
+    // a wavefront works CURV_PER_WAVE samples and adds once: thousands of atomics on ONE address serialise at ~12 ns each
+    // (8 192 single-sample wavefronts: 210 us per step, a third of an eight-rank job's step kernel)
+    constexpr int CURV_PER_WAVE = 8;
     const int lane = lane_id();
     const int64_t w0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (w0 >= n_samples || e <= b) return;
-    const int64_t t = b + (w0 * (e - b)) / n_samples;
-    const int32_t jraw = slot_neg[t];
-    if (jraw < 0) return;
-    const int64_t ou = (int64_t)slot_user[t] * K, oi = (int64_t)slot_item[t] * K, oj = (int64_t)(jraw & 0x3fffffff) * K;
-    float px = 0.0f, pw = 0.0f;
-    for (int k = lane; k < K; k += 64) {
-        const float wv = W[ou + k];
-        px += wv * (H[oi + k] - H[oj + k]);
-        pw += wv * wv;
+    if (e <= b) return;
+    float acc = 0.0f, cnt = 0.0f;
+    for (int q = 0; q < CURV_PER_WAVE; ++q) {
+        const int64_t smp = w0 * CURV_PER_WAVE + q;
+        if (smp >= n_samples) break;
+        const int64_t t = b + (smp * (e - b)) / n_samples;
+        const int32_t jraw = slot_neg[t];
+        if (jraw < 0) continue;
+        const int64_t ou = (int64_t)slot_user[t] * K, oi = (int64_t)slot_item[t] * K, oj = (int64_t)(jraw & 0x3fffffff) * K;
+        float px = 0.0f, pw = 0.0f;
+        for (int k = lane; k < K; k += 64) {
+            const float wv = W[ou + k];
+            px += wv * (H[oi + k] - H[oj + k]);
+            pw += wv * wv;
+        }
+        const float x = wave_sum(px), w2 = wave_sum(pw);
+        const float sg = 1.0f / (1.0f + __expf(x));
+        acc += sg * (1.0f - sg) * w2;
+        cnt += 1.0f;
     }
-    const float x = wave_sum(px), w2 = wave_sum(pw);
-    const float sg = 1.0f / (1.0f + __expf(x));
-    if (lane == 0) {
-        atomicAdd(out, sg * (1.0f - sg) * w2);
-        atomicAdd(out + 1, 1.0f);
+    if (lane == 0 && cnt > 0.0f) {
+        atomicAdd(out, acc);
+        atomicAdd(out + 1, cnt);
     }
 }
 
@@ -742,6 +752,7 @@ struct cymf_bpr {
     double lr = 0, wd = 0;
     uint32_t seed = 1234;
     hipStream_t stream = nullptr, rng_stream = nullptr;
+    int prio_side = 0, prio_comm = 0;                          // stream priorities (see cymf_bpr_create)
     hipStream_t gen_stream = nullptr;                          // batched index-stream generation (draw_batch > 1), beside the sampling
     hipEvent_t ev_batch_sampled[2] = {nullptr, nullptr};       // the last epoch of a batch of draws has been sampled (buffer reusable)
     BprStore<float> f32;
@@ -1336,8 +1347,8 @@ int run_one_step(cymf_bpr *h, int32_t fuse = 1) {
             float *tail = (h->overlap_exchange ? h->d_local[(int)(h->exch_count & 1)].p : h->d_delta.p) + n;
             CYMF_HIP(hipMemsetAsync(tail, 0, DELTA_TAIL * sizeof(float), h->stream));
             if (h->rho_lr_data > 0.0) {
-                const int64_t n_samples = std::min<int64_t>(e - b, 8192);
-                hipLaunchKernelGGL(bpr_curvature_kernel, dim3((unsigned)((n_samples + 3) / 4)), dim3(256), 0, h->stream, h->f32.W.p, h->f32.H.p, h->K,
+                const int64_t n_samples = std::min<int64_t>(e - b, 2048);   // a mean over 2 048 triplets: a few per cent of noise on a damping factor
+                hipLaunchKernelGGL(bpr_curvature_kernel, dim3((unsigned)((n_samples + 31) / 32)), dim3(256), 0, h->stream, h->f32.W.p, h->f32.H.p, h->K,
                                    h->d_slot_user.p, h->d_slot_item.p, h->d_slot_neg[(int)(h->epoch_cursor & 1)].p, b, e, n_samples, tail);
                 CYMF_HIP(hipGetLastError());
             }
@@ -1635,8 +1646,17 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
     cymf_bpr *h = new cymf_bpr();
     h->U = U; h->I = I; h->K = K; h->opt = optimizer; h->lr = learning_rate; h->wd = weight_decay;
     h->seed = neg_seed; h->dtype = dtype; h->mode = mode; h->device = device;
+    // Stream priorities, not for the scheduling order but for the hardware queues: the runtime deals a process's streams onto a
+    // handful of hardware queues, and two streams that land on ONE queue run strictly one after the other.  Measured in the
+    // eight-rank schedule (rocprofv3 kernel trace): the side stream (index stream, skip tests) shared a queue with the step
+    // stream and every "hidden" side kernel sat between two steps -- 0.5 ms of a 1.0 ms step.  Streams of different priority
+    // never share a queue: steps normal, side work lowest, the exchange highest.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    h->prio_side = prio_least;
+    h->prio_comm = prio_greatest;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->rng_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->rng_stream, hipStreamNonBlocking, h->prio_side);
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
         e = hipEventCreateWithFlags(&h->ev_gen[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming);
@@ -1739,7 +1759,7 @@ extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_
         if (!big && h->mode == CYMF_MODE_THROUGHPUT && N_global > 0 && !getenv("CYMF_BPR_NO_DRAW_BATCH"))
             h->draw_batch = std::max<int64_t>(2, std::min<int64_t>(64, (((int64_t)4 << 20) + N_global - 1) / N_global));
         if (h->draw_batch > 1 && !h->gen_stream) {
-            CYMF_HIP(hipStreamCreateWithFlags(&h->gen_stream, hipStreamNonBlocking));
+            CYMF_HIP(hipStreamCreateWithPriority(&h->gen_stream, hipStreamNonBlocking, h->prio_side));
             for (int b = 0; b < 2; ++b) CYMF_HIP(hipEventCreateWithFlags(&h->ev_batch_sampled[b], hipEventDisableTiming));
         }
         CYMF_TRY(h->rng.init(h->seed, (uint64_t)h->I, h->draw_batch > 1 ? h->gen_stream : h->rng_stream, /*parallel=*/big || h->draw_batch > 1));
@@ -1921,7 +1941,7 @@ extern "C" int cymf_bpr_attach_comm(cymf_bpr *h, cymf_comm *c) {
     h->comm = c;
     if (const char *e = getenv("CYMF_BPR_SYNC_EXCHANGE")) h->overlap_exchange = !(e[0] == '1');
     if (h->overlap_exchange && !h->comm_stream) {
-        hipError_t e = hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking);
+        hipError_t e = hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, h->prio_comm);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta_ready, hipEventDisableTiming);
         for (int b = 0; b < 2 && e == hipSuccess; ++b) e = hipEventCreateWithFlags(&h->ev_reduced[b], hipEventDisableTiming);
         if (e != hipSuccess) return fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e));

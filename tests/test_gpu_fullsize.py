@@ -125,17 +125,32 @@ def test_c3_lock_free_quality_at_the_benchmarked_wave_count(monkeypatch):
 
 def test_c3_eight_virtual_ranks_track_the_single_rank():
     """The multi-GPU schedule at the benchmarked shape (1M x 100k, 100M interactions, K=128, not a scaled-down problem):
-    eight ranks as eight host threads on one device (local-group communicator), users sharded by nnz, 3 steps per epoch
-    (= 25 / 8), damped item-delta sums exchanged under the next step.  Synchronous mini-batches of 33 M triplets on the
-    item table are behind the single rank's 4 M-triplet steps early on (measured after three epochs: loss 0.315 against
-    0.303, +3.9 %, the gap shrinking from +24 % after the first; the damped sums let the popular items' rows grow more slowly:
-    norm of H 0.76 of the single rank's) and converge towards it -- held-out Recall@5 is already the same, 0.4379 against 0.4383; the bar here: loss within 6 %, held-out Recall@5 within
-    0.03, norm of H within 30 %, item replicas identical on all ranks."""
+    eight ranks as eight host threads on one device (local-group communicator), users sharded by nnz, TEN steps per epoch
+    (what bench.py --gpus 8 --steps 20 runs; the rule there: at least 6), item-delta sums exchanged under the next step, their sequentialisation
+    factors from the data term MEASURED at every step (bpr_curvature_kernel).
+    What is compared is the state of the MODEL after three epochs: the BPR loss of the downloaded factors on a fixed sample of
+    2 M training triplets (within 2 % of the single rank's), the norm of H (within 10 %), held-out Recall@5 (within 0.01), item
+    replicas identical on all ranks.  The ONLINE epoch losses the trainers report are each triplet's loss against the factors
+    as they stand when it is worked -- for a rank, against its own replica of H, which inside a step has seen only that rank's
+    share of the updates -- and stay ~6 % above the single rank's after three epochs whatever the number of steps (the take-off
+    from the tiny initial factors compounds more slowly in eight replicas: +25 % after the first epoch); bounded here at 8 %.
+    Table over 3 / 6 / 12 steps per epoch: tools/c3_ranks_table.py -> profiles/r03_c3_eight_ranks.md."""
     import threading
     from cymf_amd import Evaluator, dist
     d = _c3_with_holdout()
     U, I, K = d["U"], d["I"], d["K"]
-    world, S, epochs = 8, 3, 3
+    world, S, epochs = 8, 10, 3
+    rs = np.random.RandomState(99)
+    pick = rs.randint(0, len(d["users"]), 2_000_000)
+    su, si, sj = d["users"][pick], d["pos"][pick], rs.randint(0, I, len(pick))
+
+    def model_loss(W, H):
+        out = 0.0
+        for b in range(0, len(su), 250_000):
+            x = np.einsum("nk,nk->n", W[su[b:b + 250_000]], H[si[b:b + 250_000]] - H[sj[b:b + 250_000]])
+            out += np.logaddexp(0.0, -x).sum()
+        return out / len(su)
+
     one = BprTrainer(U, I, K, "sgd", 0.05, 0.01, mode="throughput", steps_per_epoch=25)
     one.set_data(d["users"], d["pos"], d["indptr"], d["cols"])
     one.upload(d["W0"], d["H0"])
@@ -143,6 +158,7 @@ def test_c3_eight_virtual_ranks_track_the_single_rank():
     W1, H1 = np.empty_like(d["W0"]), np.empty_like(d["H0"])
     one.download(W1, H1)
     one.close()
+    m1 = model_loss(W1, H1)
     comms = dist.Comm.local_group(world, I * K + 64)
     shards = dist.user_shards(d["indptr"], world)
     res, err = [None] * world, []
@@ -175,16 +191,18 @@ def test_c3_eight_virtual_ranks_track_the_single_rank():
     H8 = res[0][2]
     assert all(np.array_equal(r[2], H8) for r in res)
     W8 = np.concatenate([r[1] for r in res])
-    np.testing.assert_allclose(job_loss[-1], loss1[-1], rtol=0.06)
+    m8 = model_loss(W8, H8)
+    print("8 virtual ranks vs 1: model loss", m8, m1, "online", job_loss, loss1, "|H|", np.linalg.norm(H8) / np.linalg.norm(H1))
+    assert abs(m8 / m1 - 1) < 0.02
+    np.testing.assert_allclose(job_loss[-1], loss1[-1], rtol=0.08)
     assert job_loss[-1] < job_loss[0] * 0.75
-    print("8 virtual ranks vs 1: loss", job_loss, loss1, "|H|", np.linalg.norm(H8) / np.linalg.norm(H1))
-    assert abs(np.linalg.norm(H8) / np.linalg.norm(H1) - 1) < 0.30
+    assert abs(np.linalg.norm(H8) / np.linalg.norm(H1) - 1) < 0.10
     ev = Evaluator(d["Xte"], d["Xtr_head"])
     n = d["n_eval_users"]
     r1, r8 = ev.evaluate(W1[:n], H1)["Recall@5"], ev.evaluate(W8[:n], H8)["Recall@5"]
     ev.close()
     print("Recall@5 single", r1, "eight ranks", r8)
-    assert abs(r1 - r8) < 0.03 and r8 > 0.15
+    assert abs(r1 - r8) < 0.01 and r8 > 0.15
 
 
 @pytest.mark.parametrize("K", [64, 128])
