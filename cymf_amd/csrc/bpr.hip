@@ -1323,8 +1323,8 @@ int run_one_step(cymf_bpr *h, int32_t fuse = 1) {
         // wavefronts = triplets in flight (4 groups x 16-slot blocks each): one or two per CU reach the atomics' rate for SGD / AdaGrad
         // (C2: 128 / 256 / 512 / 1 024 wavefronts 0.47 / 0.27 / 0.24 / 0.25 ms per epoch);
         // small data sets get fewer (the front should stay a few percent of an epoch), and Adam -- whose first moment remembers
-        // ten updates -- about half a percent of an epoch (measurements: bpr_groups.hip header)
-        const int64_t slots_per_wave = h->opt == CYMF_OPT_ADAM ? 12800 : 1024;
+        // ten updates -- about one percent of an epoch (measurements: bpr_groups.hip header)
+        const int64_t slots_per_wave = h->opt == CYMF_OPT_ADAM ? 6400 : 1024;   // (C2 Adam: 73 wavefronts, ~1 % of an epoch in flight)
         const int n_waves = h->group_waves > 0 ? h->group_waves
                                                : (int)std::max<int64_t>(1, std::min<int64_t>(512, h->N / slots_per_wave));
         BprGroupSample smp;

@@ -114,6 +114,17 @@ struct DevBuf {
     }
 };
 
+// A side stream: lowest priority.  Not for the scheduling order but for the HARDWARE QUEUES: the runtime deals a process's
+// streams onto a handful of hardware queues, and two streams that land on one queue run strictly one after the other -- the
+// "hidden" side work then sits between the main stream's kernels (measured: rocprofv3 kernel trace of the eight-rank BPR
+// schedule).  Streams of different priority never share a queue.  high = true: highest priority instead
+// (the exchange of a sharded job).
+inline hipError_t create_side_stream(hipStream_t *s, bool high = false) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, high ? greatest : least);
+}
+
 // ------------------------------------------------------------------ wave64 helpers (device)
 #if defined(__HIPCC__)
 

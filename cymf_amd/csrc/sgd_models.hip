@@ -1349,7 +1349,7 @@ extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t
     h->tile_ok = !h->force_wide_cells && mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && relmf_tile_plan(U, I, K, optimizer, &h->plan) &&
                  !(getenv("CYMF_RELMF_NO_TILES") && getenv("CYMF_RELMF_NO_TILES")[0] == '1');
     if (!rc && (h->step_path || h->tile_ok)) {
-        hipError_t e2 = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking);
+        hipError_t e2 = create_side_stream(&h->side_stream);
         for (int b = 0; b < 2 && e2 == hipSuccess; ++b) {
             e2 = hipEventCreateWithFlags(&h->ev_bucketed[b], hipEventDisableTiming);
             if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&h->ev_step_done[b], hipEventDisableTiming);

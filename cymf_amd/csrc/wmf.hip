@@ -1573,7 +1573,7 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     const char *e9 = getenv("CYMF_WMF_SEG_STREAM");
     if (!(e9 && e9[0] == '0')) {
-        if (hipStreamCreateWithFlags(&h->seg_stream, hipStreamNonBlocking) != hipSuccess ||
+        if (create_side_stream(&h->seg_stream) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_segs, hipEventDisableTiming) != hipSuccess) {
             cymf_wmf_destroy(h);
