@@ -132,6 +132,35 @@ def test_negative_stream_bit_exact_with_parallel_generator():
     t.close()
 
 
+@pytest.mark.parametrize("groups,n_target,epochs,check", [("1", 20000, 135, (0, 1, 63, 64, 65, 127, 128, 129, 134)),     # batches of 64 epochs
+                                                          ("0", 20000, 70, (0, 63, 64, 69)),                            # the same batches behind the sampling kernel
+                                                          ("1", 1_200_000, 10, (0, 1, 3, 4, 5, 7, 8, 9))])             # batches of 4 epochs, chunked generator
+def test_negative_stream_bit_exact_across_draw_batches(groups, n_target, epochs, check, monkeypatch):
+    """Small epochs draw their negatives from BATCHES of epochs generated at once on a third stream, one batch ahead, into two
+    buffers that are reused (request_epoch_draws, csrc/bpr.hip): the negatives of the epochs on either side of every batch
+    boundary -- and of a buffer's second life -- must be the one global stream's draws at their positions, bit for bit, whether
+    the group kernel resolves them itself (groups = 1) or the sampling kernel does (groups = 0)."""
+    monkeypatch.setenv("CYMF_BPR_GROUPS", groups)
+    X = synthetic.implicit_matrix(500, 300, n_target, 9) if n_target < 100000 else synthetic.implicit_matrix(40000, 4000, n_target, 19)
+    users, pos, indptr, indices = _trainer_inputs(X)
+    N, (U, I) = len(users), X.shape
+    W0, H0 = oracle.reference_init(U, I, 8)
+    t = BprTrainer(U, I, 8, "sgd", 0.01, 0.01, mode="throughput", steps_per_epoch=16)
+    t.set_data(users, pos, indptr, indices)
+    t.upload(W0, H0)
+    n_skipped = 0
+    for ep in range(epochs):
+        t.epochs(1)
+        neg = oracle.uniform_stream(1234, I, N, skip=ep * N).astype(np.int32)
+        hit = np.asarray(X[users, neg]).ravel() != 0
+        n_skipped += int(hit.sum())
+        if ep in check:
+            assert np.array_equal(t.last_negatives(), np.where(hit, -1, neg)), ep
+    performed, skipped = t.stats()
+    assert skipped == n_skipped and performed == epochs * N - n_skipped
+    t.close()
+
+
 def test_empty_and_ragged_inputs():
     # users without positives, an item nobody touched, and a 1-triplet problem
     from scipy import sparse
