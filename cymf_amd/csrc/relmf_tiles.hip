@@ -302,6 +302,7 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     const int n_workers = n_waves * WPW, worker = wave * WPW + row;
     const int lane_off = CH * l16;
     float loss_u = 0.0f;
+    unsigned int dbg_retries = 0, dbg_draws = 0;   // (developer counters, reported with CYMF_RELMF_TILE_STAMPS=1)
     using f2 = __attribute__((ext_vector_type(2))) float;
     f2 pl_acc2[EPL / 2];                                         // l2 term of all draws, one packed accumulator per register pair
 #pragma unroll
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
                     unsigned long long *a = reinterpret_cast<unsigned long long *>(sh + loc);
                     unsigned long long old = p_old[pr], seen = p_seen[pr];
                     while (seen != old) {      // somebody else updated the words meanwhile: add the deltas to what is there now
+                        ++dbg_retries;
                         old = seen;
                         seen = atomicCAS(a, old, pack2(__uint_as_float((unsigned int)old) + p_dlt[e0], __uint_as_float((unsigned int)(old >> 32)) + p_dlt[e0 + 1]));
                     }
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
                 }
                 p_il = il;
                 pend = true;
+                ++dbg_draws;
                 // the same item twice in a row (last item of one pass, first of the next): the early read of its row
                 // predates the update just issued
                 if (il_n == il) {
@@ -513,6 +516,10 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     const float l2 = wave_sum(pl_acc), lu = wave_sum(loss_u) * (1.0f / (float)LPD);
     if (lane == 0) atomicAdd(loss_acc, (double)(lu + d.p.wd * l2));
     stamp(5);
+    if (stamps) {   // compare-and-swap retries per lane and pair of words, and draws per lane, summed over the launch
+        atomicAdd(reinterpret_cast<unsigned long long *>(stamps) + 6, (unsigned long long)dbg_retries);
+        atomicAdd(reinterpret_cast<unsigned long long *>(stamps) + 7, (unsigned long long)dbg_draws);
+    }
 }
 
 size_t tile_lds_bytes(const RelTilePlan &p) {
@@ -661,6 +668,7 @@ int relmf_tile_epoch(const RelTilePlan &p, const RelTileParams &prm, const RelTi
     long long *stamps = nullptr;
     if (want_stamps) {
         CYMF_TRY(stamp_buf.alloc(16));
+        CYMF_TRY(stamp_buf.zero(s));
         stamps = stamp_buf.p;
     }
     for (int st = 0; st < p.B; ++st) {
@@ -681,6 +689,8 @@ int relmf_tile_epoch(const RelTilePlan &p, const RelTileParams &prm, const RelTi
             fprintf(stderr, "[relmf tile stamps, last sub-step, workgroup 0, %s wave] load+sort %lld, first fetch %lld, users %lld, barrier %lld, write-back %lld cycles\n",
                     w ? "last" : "first", h[8 * w + 1] - h[8 * w], h[8 * w + 2] - h[8 * w + 1], h[8 * w + 3] - h[8 * w + 2], h[8 * w + 4] - h[8 * w + 3],
                     h[8 * w + 5] - h[8 * w + 4]);
+        fprintf(stderr, "[relmf tile stamps, whole epoch] compare-and-swap retries per draw and word pair: %.4f (%lld retries, %lld lane-draws)\n",
+                h[7] ? (double)h[6] / (double)h[7] / 2.0 : 0.0, h[6], h[7]);
     }
     return 0;
 }
