@@ -100,6 +100,22 @@ for p, _ in PHASES:
                                                                   if fv[p].get(k) and wv[p].get(k) else None}
                                                               for k, v in dur[p].items() if sum(v) >= 20.0}}
     lines += ["", f"all kernels of the phase except set-up copies / casts: {tot_bytes/1e9:.3f} GB", ""]
+# the headline's dominant kernel over the TIMED launches only (the stats row includes the warm-up launches and the first-launch
+# outlier), next to what bench.py measured with HIP events in the same profiled run (<root>/stats.json)
+try:
+    timed = [d_ for _, k, _, d_ in st if re.match(r"bpr_step_kernel<\d+, \w+, 0,", k)]
+    line = json.loads(open(os.path.join(root, "stats.json")).read().strip().splitlines()[-1])
+    n_t = int(line["roofline"]["launches"])
+    if len(timed) >= n_t:
+        mean_t = sum(timed[-n_t:]) / n_t
+        # the C3 Adam leg launches the OPT=2 instantiation, so the last n_t OPT=0 launches are the timed window
+        lines += ["## headline kernel, timed window", "",
+                  f"`bpr_step_kernel` (SGD), the {n_t} timed launches of the kernel-trace pass: **{mean_t / 1e3:.3f} ms** per launch (rocprofv3); the same run's "
+                  f"bench line, HIP events on the kernel's stream: **{line['roofline']['avg_launch_ms']:.3f} ms** "
+                  f"(`roofline.achieved` {line['roofline']['achieved']:.0f} GB/s, frac {line['roofline']['frac']:.3f}; value {line['value'] / 1e9:.3f} G/s under the profiler).", ""]
+except Exception as e:   # pragma: no cover
+    lines += [f"(headline agreement not computed: {e})", ""]
+
 # what bench.py reads: bytes per unit of each roofline's launch definition
 #   (phase, dominant kernel, launches of it per epoch, what `traffic` means in bench.py's line)
 UNITS = [("C3_sgd", r"bpr_step_kernel", None, "per launch of bpr_step_kernel"), ("C3_adam", r"bpr_step_kernel", None, "per launch of bpr_step_kernel"),
