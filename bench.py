@@ -571,10 +571,9 @@ def secondary_paths(device, scale=1.0):
                 "roofline": dict(_hbm_roofline(U * I, 16 * K + 8, ms, "relmf_tile_kernel (+ tile_count / tile_scatter / index-stream kernels)"),
                                  traffic=_static_traffic("RelMF")[0] if scale == 1.0 else None, traffic_source=_static_traffic("RelMF")[1],
                                  bound_note="the algorithmic-byte figure is what SURVEY.md 8d defines, not a utilisation: a tile's item rows live in LDS and reach HBM "
-                                            "once per tile (~31 draws per row), so real HBM traffic is ~1/10 of it (`traffic`); the tile kernel is a latency chain "
-                                            "(LDS read -> dot -> DPP sum -> compare-and-swap, ~50 wave-instructions per step of four draws) -- neither the LDS "
-                                            "pipe (~1 KB per draw = 160 GB per epoch against ~79 TB/s) nor instruction issue (~2 G wave-instructions against "
-                                            "2 458 G/s) is within an order of magnitude of its peak")}
+                                            "once per tile (~31 draws per row), so real HBM traffic is ~1/10 of it (`traffic`) and the figure can exceed 1; the tile kernel is "
+                                            "bound by instruction issue and LDS latency (LDS read -> dot -> DPP sum -> integer LDS atomic add, ~100 VALU wave-instructions "
+                                            "per step of four draws; two wavefronts per SIMD keep the VALU busy), beside ~6 ms of index-stream and bucketing kernels per epoch")}
 
     attempt("C2_bpr_k64", c2_bpr)
     attempt("C2_bpr_adam_k64", lambda: c2_bpr("adam", 0.002))     # the reference's default optimizer (cymf/bpr.pyx:50)

@@ -238,6 +238,21 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     constexpr int WPW = 64 / LPD;                    // workers per wavefront
     constexpr int WPL = CH / 4;                      // words of byte counters per lane (CH items per lane)
     constexpr float SFILL = OPT == CYMF_OPT_ADAGRAD ? 1.0f : 0.0f;   // lanes past K of state rows (rows.h: Row::load)
+    // FX (SGD, AdaGrad): the tile's item rows live in LDS as FIXED-POINT integers and every update is an integer LDS atomic add --
+    // commutative, lossless, at the full LDS rate (2 cycles per CU instruction, tools/micro/lds_atomics.hip) and without a return
+    // value to wait for.  The float version added a row's delta with a compare-and-swap on the words it had READ a step earlier
+    // (the software pipeline): with 40 workers on 32 item rows somebody else had touched the row in between for 62 % of the
+    // swaps (counted: 2.47 retries per lane and draw with AdaGrad), each retry a dependent LDS round trip.
+    //   rows: int32 with ONE power-of-two scale per item row, chosen when the tile is loaded so that the row's largest entry
+    //     (floored at 2^-6) lies in [2^27, 2^28): resolution max|h| * 2^-28 -- below float32's own for every entry of the row --
+    //     with a factor of eight of head-room inside the tile visit (an entry that ends beyond 2^30 fails the epoch through
+    //     err = 3 rather than risk a wrap); block floating point instead of one fixed scale because the initial factors are
+    //     ~1e-3 / K and updates of 1e-9 must still add up (the lr -> 0 test of tests/test_gpu_models.py);
+    //   AdaGrad's accumulator, a sum that only grows and may grow a thousandfold inside one visit: int64 in units of 2^-32
+    //     (ds_add_u64: measurably slower than the 32-bit adds -- rows in int64 too cost 22.3 instead of 19 ms per epoch).
+    // Adam's moments are not additive: its rows stay float with the compare-and-swap path below.
+    constexpr bool FX = OPT != CYMF_OPT_ADAM;
+    constexpr float FX_S = 4294967296.0f, FX_FRAC = 2.3283064365386963e-10f;   // the int64 accumulators' unit
     extern __shared__ unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, n_waves = nthreads >> 6;
     const int b = blockIdx.x, bp = (b + shift) % d.B;
@@ -253,20 +268,49 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
     };
     stamp(0);
     const int K = d.K;
-    float *sh = reinterpret_cast<float *>(smem);                 // [ib][RS] item rows
-    float *ss0 = sh + (size_t)d.ib * RS;                          // [ib][RS] optimizer state 0 (NS >= 1)
-    float *ss1 = ss0 + (NS >= 1 ? (size_t)d.ib * RS : 0);         // [ib][RS] optimizer state 1 (NS == 2)
-    float *s_q = sh + (size_t)(1 + NS) * d.ib * RS;               // [ub][ib]
+    float *sh = reinterpret_cast<float *>(smem);                 // [ib][RS] item rows (FX: int32 block floating point)
+    int *shi = reinterpret_cast<int *>(smem);
+    float *ss0 = sh + (size_t)d.ib * RS;                          // [ib][RS] optimizer state 0 (NS >= 1; AdaGrad: int64 fixed point)
+    long long *sa64 = reinterpret_cast<long long *>(ss0);
+    constexpr int S0W = (OPT == CYMF_OPT_ADAGRAD) ? 2 : (NS >= 1 ? 1 : 0);   // 4-byte words per element of state 0
+    float *ss1 = ss0 + (size_t)S0W * d.ib * RS;                   // [ib][RS] optimizer state 1 (NS == 2)
+    float *s_q = ss1 + (NS == 2 ? (size_t)d.ib * RS : 0);         // [ub][ib]
     uint32_t *s_cc = reinterpret_cast<uint32_t *>(s_q + (size_t)d.ub * d.ib);   // [ub][16] words = [ub][16 lanes][4 byte counters]
+    float2 *s_scale = reinterpret_cast<float2 *>(s_cc + (size_t)d.ub * 16);     // [ib] FX: (scale, 1 / scale) of every item row
+    uint32_t *s_rowmax = reinterpret_cast<uint32_t *>(s_scale + d.ib);          // [ib] FX: bits of the row's largest |entry|
     const uint32_t I = (uint32_t)d.I;
 
+    if constexpr (FX) {   // the scale of every row: largest |entry| (an LDS integer max over the float bits), floored at 2^-6
+        for (int e = tid; e < d.ib; e += nthreads) s_rowmax[e] = 0u;
+        __syncthreads();
+        for (int e = tid; e < ni * RS; e += nthreads) {
+            const int row = e / RS, k = e - row * RS;
+            if (k < K) {
+                const float hv = d.p.H[(int64_t)(i0 + row) * K + k];
+                if (!(fabsf(hv) < 1.0e9f)) atomicExch(err, 3);   // NaN / Inf: fail, never convert
+                atomicMax(&s_rowmax[row], __float_as_uint(fabsf(hv)));
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < d.ib; e += nthreads) {
+            int ex = 0;
+            (void)frexpf(fmaxf(__uint_as_float(s_rowmax[e]), 0.015625f), &ex);   // max = f * 2^ex, f in [0.5, 1)
+            s_scale[e] = make_float2(ldexpf(1.0f, 28 - ex), ldexpf(1.0f, ex - 28));
+        }
+        __syncthreads();
+    }
     for (int e = tid; e < ni * RS; e += nthreads) {               // the tile's item rows (+ state) -> LDS
         const int row = e / RS, k = e - row * RS;
         const bool in = k < K;
         const int64_t g = (int64_t)(i0 + row) * K + k;
-        sh[e] = in ? d.p.H[g] : 0.0f;
-        if constexpr (NS >= 1) ss0[e] = in ? d.p.H0[g] : SFILL;
-        if constexpr (NS == 2) ss1[e] = in ? d.p.H1[g] : 0.0f;
+        if constexpr (FX) {
+            shi[e] = in ? __float2int_rn(d.p.H[g] * s_scale[row].x) : 0;
+            if constexpr (OPT == CYMF_OPT_ADAGRAD) sa64[e] = (long long)((double)(in ? d.p.H0[g] : SFILL) * 4294967296.0);
+        } else {
+            sh[e] = in ? d.p.H[g] : 0.0f;
+            if constexpr (NS >= 1) ss0[e] = in ? d.p.H0[g] : SFILL;
+            if constexpr (NS == 2) ss1[e] = in ? d.p.H1[g] : 0.0f;
+        }
     }
     // q_ui = x_ui / max(p_i, M) of the tile's cells (cymf/model.pyx:117), staged once: a draw then costs one LDS read
     for (int e = tid; e < nu * d.ib; e += nthreads) {
@@ -323,7 +367,7 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
             g.w1[e] = (NS == 2 && in) ? d.p.W1[base + k] : 0.0f;
         }
     };
-    struct ItemRegs { float h[EPL], t0[EPL], t1[EPL], q; int il; };
+    struct ItemRegs { float h[EPL], t0[EPL], t1[EPL], q; int il; float2 sc; };
     UserRegs nxt;
     fetch_user(worker, nxt);
     stamp(2);
@@ -368,12 +412,25 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
             g.il = il;
             const int a = il < 0 ? 0 : il;
             g.q = s_q[cu.ul * d.ib + a];
+            if constexpr (FX) g.sc = s_scale[a];
 #pragma unroll
             for (int jv = 0; jv < R * WPL; ++jv) {               // jv: float4 number jv % WPL of block jv / WPL
                 const int off = a * RS + 64 * (jv / WPL) + lane_off + 4 * (jv % WPL), e = 4 * jv;
+                if constexpr (FX) {
+                    const int4 v = *reinterpret_cast<const int4 *>(shi + off);
+                    g.h[e] = (float)v.x * g.sc.y; g.h[e + 1] = (float)v.y * g.sc.y; g.h[e + 2] = (float)v.z * g.sc.y; g.h[e + 3] = (float)v.w * g.sc.y;
+                    if constexpr (OPT == CYMF_OPT_ADAGRAD) {   // int64 with 32 fractional bits: (float) integer part + (float) fraction * 2^-32
+                        const int4 a = *reinterpret_cast<const int4 *>(sa64 + off), b = *reinterpret_cast<const int4 *>(sa64 + off + 2);
+                        g.t0[e] = fmaf((float)(unsigned int)a.x, FX_FRAC, (float)a.y);
+                        g.t0[e + 1] = fmaf((float)(unsigned int)a.z, FX_FRAC, (float)a.w);
+                        g.t0[e + 2] = fmaf((float)(unsigned int)b.x, FX_FRAC, (float)b.y);
+                        g.t0[e + 3] = fmaf((float)(unsigned int)b.z, FX_FRAC, (float)b.w);
+                    }
+                } else {
                 const float4 v = *reinterpret_cast<const float4 *>(sh + off);
                 g.h[e] = v.x; g.h[e + 1] = v.y; g.h[e + 2] = v.z; g.h[e + 3] = v.w;
                 if constexpr (NS >= 1) { const float4 s4 = *reinterpret_cast<const float4 *>(ss0 + off); g.t0[e] = s4.x; g.t0[e + 1] = s4.y; g.t0[e + 2] = s4.z; g.t0[e + 3] = s4.w; }
+                }
                 if constexpr (NS == 2) { const float4 s4 = *reinterpret_cast<const float4 *>(ss1 + off); g.t1[e] = s4.x; g.t1[e + 1] = s4.y; g.t1[e + 2] = s4.z; g.t1[e + 3] = s4.w; }
             }
         };
@@ -444,8 +501,18 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
                     hnew[e] = hv; s0n[e] = NS >= 1 ? cur.t0[e] : 0.0f; s1n[e] = NS == 2 ? cur.t1[e] : 0.0f;
                     opt_update<float, OPT, true>(d.p.opt, hnew[e], s0n[e], s1n[e], gh);
                 }
-                // AdaGrad's accumulator is a sum of g^2: added losslessly like the row; Adam's moments are not additive and
-                // are stored as this worker's consistent pair (as in the other lock-free kernels)
+                if constexpr (FX) {   // integer atomic adds of the row's (and AdaGrad's accumulator's) increments: no return, no retry
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const int loc = il * RS + 64 * (e / CH) + lane_off + (e % CH);
+                        atomicAdd(shi + loc, __float2int_rn((hnew[e] - cur.h[e]) * cur.sc.x));
+                        if constexpr (OPT == CYMF_OPT_ADAGRAD)
+                            atomicAdd(reinterpret_cast<unsigned long long *>(sa64 + loc), (unsigned long long)__float2ll_rn((s0n[e] - cur.t0[e]) * FX_S));
+                    }
+                    ++dbg_draws;
+                } else {
+                // Adam's moments are not additive and are stored as this worker's consistent pair (as in the other lock-free
+                // kernels); its row takes the step through a compare-and-swap that is not retried (see settle)
 #pragma unroll
                 for (int pr = 0; pr < EPL / 2; ++pr) {
                     const int e0 = 2 * pr, loc = il * RS + 64 * (e0 / CH) + lane_off + (e0 % CH);
@@ -465,6 +532,7 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
                 p_il = il;
                 pend = true;
                 ++dbg_draws;
+                }
                 // the same item twice in a row (last item of one pass, first of the next): the early read of its row
                 // predates the update just issued
                 if (il_n == il) {
@@ -505,9 +573,16 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
         const int row2 = e / RS, k = e - row2 * RS;
         if (k < K) {
             const int64_t g = (int64_t)(i0 + row2) * K + k;
-            d.p.H[g] = sh[e];
-            if constexpr (NS >= 1) d.p.H0[g] = ss0[e];
-            if constexpr (NS == 2) d.p.H1[g] = ss1[e];
+            if constexpr (FX) {
+                const int hv_i = shi[e];
+                if (hv_i > (1 << 30) || hv_i < -(1 << 30)) atomicExch(err, 3);   // grew more than fourfold inside one tile visit: too close to a wrap
+                d.p.H[g] = (float)hv_i * s_scale[row2].y;
+                if constexpr (OPT == CYMF_OPT_ADAGRAD) d.p.H0[g] = (float)((double)sa64[e] * (1.0 / 4294967296.0));
+            } else {
+                d.p.H[g] = sh[e];
+                if constexpr (NS >= 1) d.p.H0[g] = ss0[e];
+                if constexpr (NS == 2) d.p.H1[g] = ss1[e];
+            }
         }
     }
     float pl_acc = 0.0f;
@@ -524,7 +599,9 @@ __global__ __launch_bounds__(MAXT) void relmf_tile_kernel(RelTileDev d, const ui
 
 size_t tile_lds_bytes(const RelTilePlan &p) {
     const int NS = p.opt == CYMF_OPT_SGD ? 0 : (p.opt == CYMF_OPT_ADAGRAD ? 1 : 2);
-    return (size_t)(1 + NS) * p.ib * p.R * 64 * sizeof(float) + (size_t)p.ub * p.ib * sizeof(float) + (size_t)p.ub * 16 * sizeof(uint32_t);
+    const int words = 1 + (p.opt == CYMF_OPT_ADAGRAD ? 2 : NS);   // AdaGrad's accumulator rows are int64 fixed point (relmf_tile_kernel: FX)
+    return (size_t)words * p.ib * p.R * 64 * sizeof(float) + (size_t)p.ub * p.ib * sizeof(float) + (size_t)p.ub * 16 * sizeof(uint32_t) +
+           (size_t)p.ib * (sizeof(float2) + sizeof(uint32_t));   // + per-row scales and maxima (FX)
 }
 
 template <typename F>
@@ -599,16 +676,17 @@ bool relmf_tile_plan(int32_t U, int32_t I, int32_t K, int opt, RelTilePlan *plan
     if (const char *el = getenv("CYMF_RELMF_TILE_LPD")) p.lpd = (atoi(el) == 8 && p.R == 1) ? 8 : 16;   // developer
     const int wpw = 64 / p.lpd;
     int best_nw = 4;
-    double best = -1.0;
-    // 16: the 1024-thread build (128 VGPRs) holds K <= 64 without spilling; eight lanes per draw with AdaGrad / Adam state: 12 (the
-    // 768-thread build, 168 VGPRs)
+    double best = 1e30;
+    // 16: the 1024-thread build holds K <= 64 without spilling; eight lanes per draw with AdaGrad / Adam state: 12 (the 768-thread build)
     const int nw_max = p.R == 1 ? ((p.lpd == 8 && opt != CYMF_OPT_SGD) ? 12 : 16) : 8;
-    for (int nw = 4; nw <= nw_max; ++nw) {
+    for (int nw = 4; nw <= nw_max; nw += 2) {   // (even counts: an odd one leaves a SIMD with a wavefront less -- 7 measured 21.1 ms where 8 takes 19.7)
+        // time ~ rounds x cost of a round.  A round's cost rises slowly up to two wavefronts per SIMD and jumps beyond: with the
+        // integer-atomic write-back (FX) two wavefronts already keep a SIMD's VALU busy.  Measured on 20000 x 8000, K = 64, SGD
+        // (80 users per block), ms per epoch / rounds: 6 wavefronts 21.8 / 4, 8: 19.7 / 3, 10: 21.7 / 2, 12: 21.1 / 2, 16: 23.6 / 2
+        // (Adam: 8: 33.9, 10: 39.4, 12: 35.1, 16: 38.4).
         const int workers = wpw * nw, rounds = (p.ub + workers - 1) / workers;
-        // fewer idle workers in the last round is worth as much as more wavefronts to hide latencies (measured on 20000 x 8000,
-        // K = 64: 7 / 14 / 16 wavefronts 32.0 / 30.3 / 30.8 ms per epoch)
-        const double eff = (double)p.ub / ((double)rounds * workers) * (0.6 + 0.4 * std::min(nw, 14) / 14.0);
-        if (eff > best + 1e-9) { best = eff; best_nw = nw; }
+        const double cost = nw <= 8 ? 3.0 + 0.45 * nw : 10.0 + 0.2 * (nw - 10);
+        if (rounds * cost < best - 1e-9) { best = rounds * cost; best_nw = nw; }
     }
     p.threads = 64 * best_nw;
     if (const char *ew = getenv("CYMF_RELMF_TILE_WAVES")) p.threads = 64 * std::min(16, std::max(1, atoi(ew)));   // developer

@@ -1317,6 +1317,8 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
     CYMF_HIP(hipMemcpyAsync(&loss, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
     if (err == 2) return fail(CYMF_ERR_HIP, "relmf: a cell was drawn more than 255 times inside one tile of one epoch (that draw was not applied)");
+    if (err == 3) return fail(CYMF_ERR_HIP, "relmf: an item factor is not finite, or grew more than fourfold inside one tile visit (the tile schedule keeps item rows in block floating point); "
+                                            "CYMF_RELMF_NO_TILES=1 runs the float kernels");
     if (err) return fail(CYMF_ERR_HIP, "relmf: the per-epoch bucketing produced an index outside its block");
     if (loss_out) *loss_out = loss;
     return 0;
