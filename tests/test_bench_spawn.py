@@ -28,6 +28,8 @@ def test_bench_gpus_2_starts_its_own_ranks_and_prints_one_line(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "strong"
     assert out["metric"].startswith("BPR triplet-updates/sec") and out["value"] > 0
     assert "RCCL" in out["config"]["sharding"] and out["cpu_baseline"] is None and out["secondary"] is None
+    # a sharded job meets about 6 times per epoch at least (here: the divisor of --steps 4 nearest to 6), whatever the batch size says
+    assert out["config"]["steps_per_epoch"] == 4 and out["epochs_covered"] == 1
     # the launcher never asked for the native library; both ranks made and destroyed a communicator and a trainer
     assert not os.path.exists(tmp_path / "launcher_loaded_lib")
     assert "rank 0/2" in r.stderr and "[bench] rank 1" not in r.stderr.replace("rank 1/2", "")

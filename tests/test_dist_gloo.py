@@ -197,3 +197,20 @@ def test_adaptive_optimizers_shard_with_private_state(optimizer, lr):
     assert out[(6, True)][1] < 0.7 * out[(6, False)][1]               # and a far lower last-epoch loss
     assert dist.delta_rho("sgd", 0.05, 0.01) == pytest.approx(0.011) and dist.delta_rho("adam", 0.001, 0.01) == pytest.approx(0.005)
     assert dist.delta_rho("adagrad", 0.05, 0.01) == pytest.approx(0.011) and dist.delta_rho("adam", 1.0, 0.01) == 0.5
+
+
+def test_delta_rho_with_a_measured_data_term():
+    """Host mirror of delta_scale_kernel (csrc/bpr.hip): rho = 2 lr wd + lr * c with c the measured mean of sigma'(x) |w|^2; with
+    the tiny initial factors (c ~ 0) only the weight decay contracts and rarely touched rows are summed plainly; round 2's
+    constant stand-in is c = 1/5; Adam has no data term."""
+    from cymf_amd import dist
+    lr, wd = 0.05, 0.01
+    assert dist.delta_rho("sgd", lr, wd) == pytest.approx(2 * lr * wd + 0.2 * lr)
+    assert dist.delta_rho("sgd", lr, wd, curvature=0.0) == pytest.approx(2 * lr * wd)
+    assert dist.delta_rho("sgd", lr, wd, curvature=0.3) == pytest.approx(2 * lr * wd + 0.3 * lr)
+    assert dist.delta_rho("adam", lr, wd, curvature=0.3) == pytest.approx(5 * lr)
+    assert dist.delta_rho("sgd", 1.0, 1.0, curvature=10.0) == 0.5                     # capped
+    n = np.array([0.0, 1.0, 100.0, 1e6])
+    s0 = dist.delta_scale(n, 8, lr, wd, curvature=0.0)
+    s3 = dist.delta_scale(n, 8, lr, wd, curvature=0.3)
+    assert s0[0] == 1.0 and (s3 <= s0 + 1e-12).all() and s3[-1] == pytest.approx(1 / 8, rel=1e-6) and s0[1] > 0.999
