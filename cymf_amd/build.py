@@ -46,7 +46,7 @@ def build(force=False, verbose=True):
         src, obj = job
         if verbose:
             print(f"[cymf_amd.build] hipcc {os.path.basename(src)}", flush=True)
-        subprocess.check_call([hipcc] + FLAGS + ["-c", src, "-o", obj])
+        subprocess.check_call([hipcc] + FLAGS + os.environ.get("CYMF_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj])   # (developer: -D switches of experiments)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
