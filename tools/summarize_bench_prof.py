@@ -97,7 +97,8 @@ for p, _ in PHASES:
             lines.append(f"| {k} | {len(v)} | {sum(v)/1e3:.3f} | {sum(v)/len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {fm:.1f} | {wm:.1f} | {b:.4g} |")
     traffic[p] = {"bytes_all_kernels": tot_bytes, "kernels": {k: {"launches": len(v), "avg_us": sum(v) / len(v),
                                                                   "bytes_per_launch": (2 * (sum(fv[p][k]) / len(fv[p][k])) + sum(wv[p][k]) / len(wv[p][k])) * 1024
-                                                                  if fv[p].get(k) and wv[p].get(k) else None}
+                                                                  if fv[p].get(k) and wv[p].get(k) else None,
+                                                                  "write_bytes_per_launch": sum(wv[p][k]) / len(wv[p][k]) * 1024 if wv[p].get(k) else None}
                                                               for k, v in dur[p].items() if sum(v) >= 20.0}}
     lines += ["", f"all kernels of the phase except set-up copies / casts: {tot_bytes/1e9:.3f} GB", ""]
 # the headline's dominant kernel over the TIMED launches only (the stats row includes the warm-up launches and the first-launch
@@ -134,7 +135,7 @@ for p, rx, per_epoch, what in UNITS:
     if per_epoch is None:
         flat[p] = {"bytes": v["bytes_per_launch"], "unit": what, "kernel": k, "avg_us": v["avg_us"]}
     elif per_epoch == 1:
-        flat[p] = {"bytes": v["bytes_per_launch"], "unit": what, "kernel": k, "avg_us": v["avg_us"]}
+        flat[p] = {"bytes": v["bytes_per_launch"], "unit": what, "kernel": k, "avg_us": v["avg_us"], "write_bytes": v["write_bytes_per_launch"]}
     else:
         epochs = v["launches"] / per_epoch
         flat[p] = {"bytes": traffic[p]["bytes_all_kernels"] / epochs, "unit": what, "kernel": k, "epochs_in_profile": epochs}
