@@ -358,18 +358,11 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 // important at K=128, half the code -- the unrolled elimination is straight-line code that every wave streams
 // through once per row, and it has to stay near the 64 KB instruction cache.  Pairs are updated whole: an entry
 // left of the pivot column is dead, so touching it is harmless.
-// (H: work of ANOTHER row folded into the column steps -- `hook.template column<C>()` runs at the head of step C, where
-// nothing of the step's own LDS traffic is outstanding yet; wmf_row_pipe64_kernel.  CH: 16-byte broadcast reads per chunk.)
-struct NoColumnHook {
-    template <int C> __device__ __forceinline__ void column() {}
-};
-
-template <int K, int NW, int C, class H = NoColumnHook, int CH_ = 8>
-__device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &mypiv, int j, float *colbuf, float *bbuf, H &hook) {
+template <int K, int NW, int C>
+__device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &mypiv, int j, float *colbuf, float *bbuf) {
     using f4 = __attribute__((ext_vector_type(4))) float;
     constexpr int KP = 64 * NW;   // one slot per lane: idle lanes (j >= K) publish into slots nobody reads, no branch
     float *cb = colbuf + (C & 1) * KP;          // column C was published by the previous step (column 0: by solve_reg)
-    hook.template column<C>();
     const float raw = a[C / 2][C & 1];
     float d, bc;
     group_sync<NW>();
@@ -389,7 +382,7 @@ __device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &m
     // The broadcast reads of the pivot row are issued a chunk (CH x 16 B) ahead of the FMAs that use them, into two
     // alternating register sets: the pins below are `asm volatile`, which no load may cross, so a read issued next to its
     // FMAs would be waited for on the spot (one full LDS latency per two v_pk_fma_f32 -- measured: the whole solve).
-    constexpr int G0 = (C + 1) / 4, G1 = K / 4, CH = CH_, NCH = (G1 - G0 + CH - 1) / CH;
+    constexpr int G0 = (C + 1) / 4, G1 = K / 4, CH = 8, NCH = (G1 - G0 + CH - 1) / CH;
     f4 buf[2][CH];
 #pragma unroll
     for (int u = 0; u < CH; ++u)
@@ -425,21 +418,16 @@ __device__ __forceinline__ void gj_column(f32x2 (&a)[K / 2], float &bj, float &m
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (C + 1 < K) gj_column<K, NW, C + 1, H, CH_>(a, bj, mypiv, j, colbuf, bbuf, hook);
+    if constexpr (C + 1 < K) gj_column<K, NW, C + 1>(a, bj, mypiv, j, colbuf, bbuf);
 }
 
-template <int K, int NW, class H, int CH_ = 8>
-__device__ __forceinline__ float solve_reg(f32x2 (&a)[K / 2], float bj, int j, float *colbuf, float *bbuf, H &hook) {
+template <int K, int NW>
+__device__ __forceinline__ float solve_reg(f32x2 (&a)[K / 2], float bj, int j, float *colbuf, float *bbuf) {
     float mypiv = 0.0f;   // 1 / pivot of this lane's row
     colbuf[j] = a[0][0];  // column 0; every later column is published by the step before it
     if (NW > 1) bbuf[j] = bj;
-    gj_column<K, NW, 0, H, CH_>(a, bj, mypiv, j, colbuf, bbuf, hook);
+    gj_column<K, NW, 0>(a, bj, mypiv, j, colbuf, bbuf);
     return bj * mypiv;
-}
-template <int K, int NW>
-__device__ __forceinline__ float solve_reg(f32x2 (&a)[K / 2], float bj, int j, float *colbuf, float *bbuf) {
-    NoColumnHook none;
-    return solve_reg<K, NW, NoColumnHook>(a, bj, j, colbuf, bbuf, none);
 }
 
 // t-th pair (m <= n) of the row-major upper triangle of a T32 x T32 tile grid
@@ -647,266 +635,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 2) void wmf_row_reg_kernel(i
         const float x = probe == 1 ? a[0][0] + bj0 : solve_reg<K, NW>(a, bj0, j, colbuf, bbuf);   // (1: timing probe, no solve)
         if (j < K) X[(int64_t)i * K + j] = x;                  // wmf.pyx:170-171
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K = 64, round 3: the solve of row r and the Gramian of row r + 1 in ONE instruction stream (wmf_row_pipe64_kernel).
-//
-// wmf_row_reg_kernel above runs two latency chains one after the other in every wave -- gather group -> its MFMAs, then 64
-// column steps of an LDS round trip each -- and three waves per SIMD do not cover them: matrix pipe busy 0.49, VALU 0.41,
-// LDS 0.36, 58 % of the wave cycles spent at an s_waitcnt (profiles/r03_wmf_k64_analysis.md).  Here
-//   * the gathered rows arrive by LDS-DMA (global_load_lds_dwordx4: lanes 16 g .. 16 g + 15 ask for the 256 bytes of gathered
-//     row g of a 4-row step; the 1 KiB lands lane-linear in a slot of a per-wave RING of R slots) and one ds_read_b128
-//     hands every lane back its own 16 bytes: the bytes in flight are LDS, not registers, the issue of step s + R is one
-//     instruction behind the consumption of step s, and nothing in the loop waits for a load it has just issued;
-//   * those 16 bytes ARE the operands: v_mfma_f32_16x16x4_f32 takes, per lane (k = l >> 4, i = l & 15), A[i][k] and B[k][j]
-//     -- with column chunk q := the columns {4 i + q} the four floats of a lane are chunks 0..3 of gathered row k, and the
-//     Gramian of 4 rows is 10 MFMAs on the upper 16 x 16 tiles (62.5 % of the square; the 32 x 32 tiling computes 75 %:
-//     343 against 409 pipe cycles per step, tools/micro/mfma_f32_tiles.hip).  The system is built and solved in that
-//     PERMUTED index space (P = 16 q + i <-> column 4 i + q; a symmetric permutation of an SPD system) and x is un-permuted
-//     by the store;
-//   * a wave issues IN ORDER, about one instruction per five cycles, and the scalar unit is shared by the CU: what bounds
-//     this loop is the number of instructions per step and their order, not a pipe (a first version with the row bookkeeping in
-//     the loop ran 92 instructions per step, half of them scalar, at 590 cycles per step and SIMD; ten MFMAs back to back hold
-//     the wave for 320 cycles while its own bookkeeping waits behind them).  So the host lays every wave's work out as ONE
-//     contiguous stream of steps -- four gathered-row indices each, a row's last step padded, rows in the order the wave takes
-//     them (wmf_pipe64_pack) -- and the issuer is a counter walking it: no row bookkeeping, no branches; the indices come
-//     through LDS as well (blocks of 64 steps by the same LDS-DMA instruction, read per lane one step ahead), so that the
-//     loop has no scalar load either -- SMEM returns out of order, every use of one is an s_waitcnt lgkmcnt(0) that also waits
-//     for the LDS reads in flight.  The MFMAs are spread over the step's other instructions (sched_group_barrier).  45
-//     instructions and 10 MFMAs per step.
-//   * the Gramian of row r + 1 FOLDED INTO the solve of row r (one 4-row step at the head of every column step, the
-//     accumulators alive beside the row registers) was built and measured: no gain -- the wave issues in order, the compiler
-//     keeps the step's instructions together, and what overlaps is different WAVES.  So the two phases stay apart, each with
-//     few registers, and more waves per SIMD run them against each other.
-// Rows are dealt statically and FOLDED: wave b takes ranks b, 2G-1-b, 2G+b, ... of the longest-first list alternately from
-// its long end and its short end, so that long Gramians meet short ones inside a wave and the wave totals are even.
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-struct WmfRowInfo { int32_t row, p0, n, pad; };   // one entry per rank of the work list (host: cymf_wmf_set_data)
-
-constexpr int P64_LD = 20;                             // stride of a staged 16 x 16 tile row (16-byte aligned, conflict-free)
-constexpr int P64_TILE = 16 * P64_LD;                  // floats
-constexpr int P64_IBLK = 64;                           // steps per block of the index ring (one LDS-DMA instruction: 64 lanes x 4 indices)
-constexpr int P64_IRING = 2 * P64_IBLK * 16;           // the index ring: two blocks
-constexpr int P64_STAGE = 2;                           // tiles staged per round of the layout change
-// one wavefront = one workgroup: ring (R slots of 1 KiB, R a power of two) | index ring | stage [P64_STAGE][16][P64_LD] | column buffers [2][64]
-constexpr size_t wmf_pipe64_smem(int R) { return (size_t)R * 1024 + P64_IRING + 4 * (size_t)(P64_STAGE * P64_TILE + 2 * 64); }
-
-typedef __attribute__((address_space(3))) unsigned char wmf_lds_u8;
-__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)(uintptr_t)(wmf_lds_u8 *)p; }
-
-// A0 / (w - 1) in the accumulator layout of v_mfma_f32_16x16x4_f32 over the permuted index space: tile t = (m <= n), lane l,
-// register r at [(t * 64 + l) * 4 + r] = A0[perm(16 m + 4 (l >> 4) + r)][perm(16 n + (l & 15))], perm(P) = 4 (P & 15) + (P >> 4).
-__global__ void wmf_tile16_layout_kernel(const float *__restrict__ A0, float inv_w1, float *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 10 * 64 * 4) return;
-    const int r = e & 3, l = (e >> 2) & 63, t = e >> 8;
-    int m = 0, n = 0;
-    for (int q = 0; q < 10; ++q)
-        if (q == t) { m = tile_m(q); n = tile_n(q); }
-    const int P = 16 * m + 4 * (l >> 4) + r, Q = 16 * n + (l & 15);
-    out[e] = A0[(4 * (P & 15) + (P >> 4)) * 64 + (4 * (Q & 15) + (Q >> 4))] * inv_w1;
-}
-
-// rows without entries: x = 0 (wmf.pyx:154-156); they sit at the end of the longest-first work list
-__global__ void wmf_zero_rows_kernel(const int32_t *__restrict__ order, int32_t n, int K, float *__restrict__ X) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (int64_t)n * K) X[(int64_t)order[e / K] * K + e % K] = 0.0f;
-}
-
-typedef const __attribute__((address_space(4))) int32_t *p64_cptr;   // constant address space: with a uniform address, a scalar load
-
-template <int P64_R>
-struct Pipe64 {
-    // ---- constants
-    const char *Yb;                           // the gathered table
-    const char *Sb;                           // the wave's stream of steps (four indices each)
-    uint32_t ring_lds, iring_lds;             // LDS byte offsets of this wave's ring and index ring
-    const unsigned char *ring_lane;           // the ring for lane l: + 16 l
-    const unsigned char *iring_lane;          // the index ring for lane l: + 4 (l >> 4) -- the index of the step's row that lane l gathers
-    int lane;
-    // ---- issuer.  The indices come through LDS as well: blocks of P64_IBLK steps, asked for (one LDS-DMA instruction each) one
-    // block ahead and read one step ahead, per lane, by a ds_read_b32.  No scalar load in the loop: SMEM returns out of order, so
-    // every use of one is an s_waitcnt lgkmcnt(0) that also waits for every LDS read in flight.
-    int32_t s_i;                              // steps asked for so far
-    int32_t req_at;                           // at s_i >= req_at (the issuer enters block req_at / P64_IBLK) the block after it is due
-    uint32_t ioff;                            // byte offset (in the index ring) of the step after the next one to ask for
-    int32_t idx_n;                            // this lane's gathered-row index of the next step to ask for
-    uint32_t soff;                            // byte offset (in the ring) of the slot the consumer holds = the slot the next issue refills
-    // ---- consumer
-    f32x4 v, vn;                              // the oldest element not yet consumed; the one after it (prefetch())
-    f32x4 acc[10];
-    f32x4 bsum;
-    int32_t c_left;                           // entries of the accumulating row not yet consumed (<= 0: none, or no such row)
-
-    __device__ __forceinline__ void lds_dma(const char *base, uint32_t off, uint32_t dst, float dep) {
-        // one LDS-DMA wave instruction: lane l's 16 bytes at base + off -> LDS byte dst + 16 l (M0 saved and restored: it is the
-        // compiler's; `dep`: a register whose value must exist first, so that the statement cannot be scheduled ahead of its wait)
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(off), "s"(dst), "s"(base), "v"(dep) : "memory");
-    }
-    __device__ __forceinline__ void request_block(int32_t blk) {
-        lds_dma(Sb, (uint32_t)blk * (P64_IBLK * 16) + (uint32_t)lane * 16u, iring_lds + (uint32_t)(blk & 1) * (P64_IBLK * 16), 0.0f);
-    }
-    __device__ __forceinline__ void request_blocks() {   // (block b + 1 lands in the half that block b - 1, all asked for, has left;
-        if (s_i >= req_at) {                             //  it is first read P64_IBLK steps and as many loads later)
-            request_block(req_at / P64_IBLK + 1);
-            req_at += P64_IBLK;
-        }
-    }
-    // One step is asked for in two halves.  step_offset(): the byte offset of the lane's 16 bytes in the table (lanes 16 g .. 16 g + 15
-    // take the row of the step's g-th index), and the read of the NEXT step's index, early in the consumer's step.
-    __device__ __forceinline__ uint32_t step_offset() {
-        const uint32_t off = (uint32_t)idx_n * 256u + (uint32_t)(lane & 15) * 16u;
-        idx_n = *reinterpret_cast<const int32_t *>(iring_lane + ioff);
-        ioff = (ioff + 16u) & (uint32_t)(P64_IRING - 1);
-        ++s_i;
-        return off;
-    }
-    __device__ __forceinline__ void dma(uint32_t off, float dep) { lds_dma(Yb, off, ring_lds + soff, dep); }
-    // v is the oldest element not yet consumed, in registers.  One element is consumed as: prefetch() -- the ds_read of the NEXT
-    // element, whose latency then lies under this element's MFMAs --, the work on v, advance() -- the slot v came from is asked
-    // for again, v <- the prefetched element.
-    __device__ __forceinline__ void first() {      // after the first P64_R issues: all but the oldest may still be in flight
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P64_R - 1) : "memory");
-        v = *reinterpret_cast<const f32x4 *>(ring_lane + soff);
-    }
-    __device__ __forceinline__ void prefetch() {   // v's slot has not been asked for again yet: P64_R - 2 loads are younger than the next element's
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P64_R - 2) : "memory");
-        vn = *reinterpret_cast<const f32x4 *>(ring_lane + ((soff + 1024u) & (uint32_t)(P64_R * 1024 - 1)));
-    }
-    __device__ __forceinline__ void data_step() {   // v = entries c .. c + 3 of the accumulating row, one per 16 lanes
-        prefetch();
-        const uint32_t off = step_offset();
-        const bool ok = (lane >> 4) < c_left;
-        const f32x4 w = {ok ? v[0] : 0.0f, ok ? v[1] : 0.0f, ok ? v[2] : 0.0f, ok ? v[3] : 0.0f};
-#pragma unroll
-        for (int t = 0; t < 10; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tile_m(t)], w[tile_n(t)], acc[t], 0, 0, 0);
-        bsum += w;
-        c_left -= 4;
-        dma(off, v[0]);
-        soff = (soff + 1024u) & (uint32_t)(P64_R * 1024 - 1);
-        v = vn;
-        // A wave issues in order: ten MFMAs back to back hold it for 320 cycles while its own bookkeeping waits behind them.
-        // One MFMA, then a few of the other instructions, ten times over.
-#pragma unroll
-        for (int t = 0; t < 10; ++t) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);   // VALU | SALU
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        }
-    }
-};
-
-template <int T0, int T1>
-__device__ __forceinline__ void p64_round(f32x2 (&a)[32], const f32x4 (&acc)[10], float *stage, float w1, int lane) {
-    const int jb = lane >> 4, jl = lane & 15;
-    group_sync<1>();
-#pragma unroll
-    for (int t = T0; t < T1; ++t) {
-        float *st = stage + (t - T0) * P64_TILE;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st[(4 * (lane >> 4) + r) * P64_LD + (lane & 15)] = acc[t][r] * w1;
-    }
-    group_sync<1>();
-#pragma unroll
-    for (int t = T0; t < T1; ++t) {
-        const int m = tile_m(t), n = tile_n(t);
-        const float *st = stage + (t - T0) * P64_TILE;
-        {
-            const bool hit = jb == m;
-            const f32x4 *row = reinterpret_cast<const f32x4 *>(st + jl * P64_LD);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 q = row[g];
-                a[8 * n + 2 * g] = hit ? f32x2{q[0], q[1]} : a[8 * n + 2 * g];
-                a[8 * n + 2 * g + 1] = hit ? f32x2{q[2], q[3]} : a[8 * n + 2 * g + 1];
-            }
-        }
-        if (m != n) {   // the mirrored block reads the tile's transpose
-            const bool hit = jb == n;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const f32x2 q = {st[2 * e * P64_LD + jl], st[(2 * e + 1) * P64_LD + jl]};
-                a[8 * m + e] = hit ? q : a[8 * m + e];
-            }
-        }
-    }
-}
-
-// One wavefront per workgroup.  Wave w of the launch: its rows are rows[row_off[w] .. row_off[w + 1]) = {row, entries}, its steps
-// steps[4 step_off[w] ...] (wmf_pipe64_pack; padding after the last one, which the issuer asks for and nobody consumes).
-template <int P64_R, int OCC>
-__global__ __launch_bounds__(64, OCC) void wmf_row_pipe64_kernel(int32_t n_waves, const int32_t *__restrict__ row_off,
-                                                                 const int32_t *__restrict__ rows, const int32_t *__restrict__ step_off,
-                                                                 const int32_t *__restrict__ steps, float *__restrict__ X,
-                                                                 const float *__restrict__ Y, const float *__restrict__ A0t,
-                                                                 float weight, int probe) {
-    constexpr int K = 64;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
-    const int lane = threadIdx.x;
-    const int32_t w = blockIdx.x;
-    unsigned char *iring = smem_raw + P64_R * 1024;
-    float *stage = reinterpret_cast<float *>(iring + P64_IRING);            // [P64_STAGE][16][P64_LD]
-    float *colbuf = stage + P64_STAGE * P64_TILE;                            // [2][64]
-    const f32x4 *a0_lane = reinterpret_cast<const f32x4 *>(A0t) + lane;
-
-    const p64_cptr rp = (p64_cptr)rows;
-    int32_t r_next = row_off[w];
-    const int32_t r_end = row_off[w + 1];
-    if (r_next >= r_end) return;
-
-    Pipe64<P64_R> p;
-    p.Yb = reinterpret_cast<const char *>(Y);
-    p.Sb = reinterpret_cast<const char *>(steps) + 16 * (int64_t)step_off[w];
-    p.ring_lds = lds_offset(smem_raw); p.ring_lane = smem_raw + lane * 16; p.lane = lane;
-    p.iring_lds = lds_offset(iring); p.iring_lane = iring + (lane >> 4) * 4;
-    p.request_block(0);
-    p.request_block(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    p.s_i = 0; p.req_at = P64_IBLK;
-    p.idx_n = *reinterpret_cast<const int32_t *>(p.iring_lane);
-    p.ioff = 16;
-#pragma unroll 1
-    for (int s = 0; s < P64_R; ++s) { p.soff = 1024u * s; p.dma(p.step_offset(), 0.0f); }
-    p.soff = 0;
-    p.first();
-    const float w1 = weight - 1.0f;
-#pragma unroll 1
-    for (; r_next < r_end; ++r_next) {
-        const int32_t row = rp[2 * r_next];
-        p.c_left = rp[2 * r_next + 1];
-        // ---- the Gramian: accumulators from A0 / (w - 1) (10 KiB, L2-resident; the ring is idle and landed at this point, so the
-        // wait for these loads drains nothing), then the row's steps
-#pragma unroll
-        for (int t = 0; t < 10; ++t) p.acc[t] = a0_lane[t * 64];
-        p.bsum = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-        while (p.c_left > 0) { p.request_blocks(); p.data_step(); }
-        // ---- lane j <- row j (permuted space) of A = A0 + (w - 1) G, b_j = w sum y
-        int j = lane;
-        asm volatile("" : "+v"(j));   // opaque per row: keeps the lane comparisons of the solve out of (spilled) SGPR pairs
-        const int jb = j >> 4, jl = j & 15;
-        group_sync<1>();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) stage[q * 64 + lane] = p.bsum[q];
-        group_sync<1>();
-        const float bj0 = ((stage[jb * 64 + jl] + stage[jb * 64 + jl + 16]) + (stage[jb * 64 + jl + 32] + stage[jb * 64 + jl + 48])) * weight;
-        f32x2 a[K / 2];
-#pragma unroll
-        for (int g = 0; g < K / 2; ++g) a[g] = f32x2{0.0f, 0.0f};
-        p64_round<0, 2>(a, p.acc, stage, w1, j);
-        p64_round<2, 4>(a, p.acc, stage, w1, j);
-        p64_round<4, 6>(a, p.acc, stage, w1, j);
-        p64_round<6, 8>(a, p.acc, stage, w1, j);
-        p64_round<8, 10>(a, p.acc, stage, w1, j);
-        group_sync<1>();
-        NoColumnHook none;
-        const float x = probe == 1 ? a[0][0] + bj0 : solve_reg<K, 1, NoColumnHook, OCC >= 4 ? 2 : 4>(a, bj0, j, colbuf, colbuf, none);   // (1: timing probe, no solve)
-        X[(int64_t)row * K + 4 * jl + jb] = x;                    // wmf.pyx:170-171; permuted row 16 q + i is column 4 i + q
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last loads must have landed before the LDS is handed on
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1608,16 +1336,6 @@ struct cymf_wmf {
     DevBuf<float> d_a0t;            // (YtY + lambda I) / (w - 1) in the accumulator tile layout (wmf_tile_layout_kernel)
     DevBuf<unsigned long long> d_ticks;   // CYMF_WMF_PROBE=5: [side][8] phase ticks of wmf_row_blk_kernel
     DevBuf<int32_t> d_order[2];     // this rank's whole rows (offsets from its first row), longest first: the row kernels' work list
-    // wmf_row_pipe64_kernel (K = 64): every wave's rows {row, entries} and its stream of 4-index steps, contiguous per wave
-    DevBuf<int32_t> d_p64_row_off[2], d_p64_rows[2], d_p64_step_off[2], d_p64_steps[2];
-    int32_t n_p64_waves[2] = {0, 0};
-    int32_t n_rowinfo[2] = {0, 0};     // this rank's whole rows with entries (the others get zeros)
-    DevBuf<float> d_a0t16;          // (YtY + lambda I) / (w - 1) in 16 x 16 accumulator tiles over the permuted index space
-    int pipe64 = 0;                 // CYMF_WMF_PIPE64=1: K = 64 on wmf_row_pipe64_kernel (experimental: parity green, slower than wmf_row_reg_kernel)
-    int pipe64_occ = 3;             // CYMF_WMF_PIPE64_OCC: its wavefronts per SIMD (3: ring of 8 slots; 4: ring of 4 slots, <= 128 VGPRs)
-    int pipe64_waves = 0;           // CYMF_WMF_PIPE64_WAVES: its wavefronts (default: what is resident); fixed at set_data
-    int pipe64_sides = 3;           // CYMF_WMF_PIPE64_SIDES: bit 0 the user sweep, bit 1 the item sweep
-    int pipe64_probe = 0;           // CYMF_WMF_PIPE64_PROBE: timing probes of wmf_row_pipe64_kernel
     int32_t n_order[2] = {0, 0};
     int32_t n_segs[2] = {0, 0}, n_long[2] = {0, 0};
     DevBuf<float> d_scratch;
@@ -1632,75 +1350,6 @@ template <typename F>
 static int allow_lds(F kernel, size_t bytes) {
     if (bytes > 48 * 1024)
         CYMF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return 0;
-}
-
-// K = 64: the whole rows of one half-sweep on wmf_row_pipe64_kernel (+ zeros for the rows without entries)
-static int launch_pipe64(cymf_wmf *h, int side, float *Xf, const float *Yf, const float *Gf) {
-    const int32_t n_live = h->n_rowinfo[side], n_empty = h->n_order[side] - n_live;
-    if (n_empty > 0) {
-        const int64_t n = (int64_t)n_empty * 64;
-        hipLaunchKernelGGL(wmf_zero_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_order[side].p + n_live, n_empty, 64, Xf);
-    }
-    if (n_live > 0) {
-        CYMF_TRY(h->d_a0t16.alloc(10 * 64 * 4));
-        hipLaunchKernelGGL(wmf_tile16_layout_kernel, dim3(10), dim3(256), 0, h->stream, Gf, (float)(1.0 / (h->weight - 1.0)), h->d_a0t16.p);
-        const int32_t n_waves = h->n_p64_waves[side];
-#define WMF_PIPE64_(R_, OCC_)                                                                                               \
-    do {                                                                                                                    \
-        const size_t smem = wmf_pipe64_smem(R_);                                                                            \
-        CYMF_TRY(allow_lds((wmf_row_pipe64_kernel<R_, OCC_>), smem));                                                       \
-        hipLaunchKernelGGL((wmf_row_pipe64_kernel<R_, OCC_>), dim3((unsigned)n_waves), dim3(64), smem, h->stream, n_waves,  \
-                           h->d_p64_row_off[side].p, h->d_p64_rows[side].p, h->d_p64_step_off[side].p, h->d_p64_steps[side].p, \
-                           Xf, Yf, h->d_a0t16.p, (float)h->weight, h->pipe64_probe);                                        \
-    } while (0)
-        if (h->pipe64_occ >= 4) WMF_PIPE64_(4, 4);
-        else WMF_PIPE64_(8, 3);
-#undef WMF_PIPE64_
-    }
-    CYMF_HIP(hipGetLastError());
-    return 0;
-}
-
-// The work of wmf_row_pipe64_kernel, laid out per wave: wave b of G takes the rows at ranks b, 2G-1-b, 2G+b, ... of the
-// longest-first list `info`, alternately from its long end (rank t) and its short end (rank n-1-t); its steps are the rows'
-// CSR entries four at a time, a row's last step padded with its last entry; padding (index 0) at the end of every wave's stream.
-static int wmf_pipe64_pack(cymf_wmf *h, int side, const std::vector<WmfRowInfo> &info, const int32_t *ix_host) {
-    const int32_t n = (int32_t)info.size();
-    h->n_p64_waves[side] = 0;
-    if (n == 0 || h->K != 64) return 0;
-    const int32_t resident = 256 * 4 * (h->pipe64_occ >= 4 ? 4 : 3);
-    const int32_t G = std::max(1, std::min(h->pipe64_waves > 0 ? h->pipe64_waves : resident, (n + 1) / 2));
-    std::vector<int32_t> row_off((size_t)G + 1, 0), step_off((size_t)G + 1, 0), rows, steps;
-    rows.reserve((size_t)n * 2);
-    int64_t total = 0;
-    for (const WmfRowInfo &r : info) total += (r.n + 3) / 4;
-    if (total + (int64_t)G * 6 * P64_IBLK >= ((int64_t)1 << 29)) return 0;   // (32-bit step offsets; such a shard takes the older kernel)
-    steps.reserve((size_t)(total + (int64_t)G * 6 * P64_IBLK) * 4);
-    for (int32_t b = 0; b < G; ++b) {
-        for (int32_t q = 0;; ++q) {
-            const int32_t k = q >> 1;
-            const int64_t t = (int64_t)k * G + ((k & 1) ? G - 1 - b : b), hi = (int64_t)n - 1 - t;
-            if ((q & 1) ? t >= hi : t > hi) break;
-            const WmfRowInfo &r = info[(size_t)((q & 1) ? hi : t)];
-            rows.push_back(r.row);
-            rows.push_back(r.n);
-            for (int32_t e = 0; e < r.n; e += 4)
-                for (int32_t c = 0; c < 4; ++c) steps.push_back(ix_host[r.p0 + std::min(e + c, r.n - 1)]);
-        }
-        // padding (index 0): the steps the issuer asks for past the end (a ring full: at most 8), up to a whole block, and the blocks it reads ahead
-        const size_t mine = steps.size() / 4 - (size_t)step_off[(size_t)b];
-        const size_t padded = (mine + 8 + P64_IBLK - 1) / P64_IBLK * P64_IBLK + 2 * P64_IBLK;
-        steps.resize(steps.size() + (padded - mine) * 4, 0);
-        row_off[(size_t)b + 1] = (int32_t)(rows.size() / 2);
-        step_off[(size_t)b + 1] = (int32_t)(steps.size() / 4);
-    }
-    if ((int64_t)rows.size() / 2 != n) return fail(CYMF_ERR_INVALID, "wmf_pipe64_pack: %zu of %d rows dealt", rows.size() / 2, n);
-    CYMF_TRY(h->d_p64_row_off[side].upload(row_off.data(), row_off.size(), h->stream));
-    CYMF_TRY(h->d_p64_rows[side].upload(rows.data(), rows.size(), h->stream));
-    CYMF_TRY(h->d_p64_step_off[side].upload(step_off.data(), step_off.size(), h->stream));
-    CYMF_TRY(h->d_p64_steps[side].upload(steps.data(), steps.size(), h->stream));
-    h->n_p64_waves[side] = G;
     return 0;
 }
 
@@ -1804,8 +1453,6 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
             } seg_join{h, ss, ss != h->stream};
             const int grid_seg = (int)std::min<int64_t>(nseg, 256 * 16);
             const bool sorted = h->row_order && h->d_order[side].p;
-            const bool pipe64 = K == 64 && h->pipe64 && ((h->pipe64_sides >> side) & 1) && h->n_p64_waves[side] > 0 && reg_ok && h->weight != 1.0 &&
-                                sorted && h->probe == 0 && h->blocked <= 0;
             const int32_t *order = sorted ? h->d_order[side].p : nullptr;
             const int32_t n_work = sorted ? h->n_order[side] : my_rows;
 #define WMF_LAUNCH_(T32_)                                                                                                   \
@@ -1825,8 +1472,6 @@ static int wmf_half(cymf_wmf *h, WmfStore<T> &st, int side) {
                                (float)(1.0 / (h->weight - 1.0)), h->d_a0t.p);                                               \
         }                                                                                                                   \
         if (my_rows <= 0) {                                                                                                 \
-        } else if ((T32_) == 2 && pipe64) {                                                                                 \
-            CYMF_TRY(launch_pipe64(h, side, Xf, Yf, Gf));                                                               \
         } else if (reg_ok && h->weight != 1.0 && (h->blocked >= 0 ? h->blocked != 0 : (T32_) >= 3)) {                      \
             const int grid_b = (int)std::max<int64_t>(1, std::min<int64_t>(n_work, 256 * 64));                              \
             hipLaunchKernelGGL((wmf_row_blk_kernel<T32_>), dim3(grid_b), dim3(64), (T32_) == 4 ? 16384 : 0, h->stream, n_work, ip, ix, Xf, Yf, h->d_a0t.p, \
@@ -1917,11 +1562,6 @@ extern "C" int cymf_wmf_create(cymf_wmf **out, int32_t U, int32_t I, int32_t K, 
     if (const char *e4 = getenv("CYMF_WMF_PROBE")) h->probe = atoi(e4);
     if (const char *e7 = getenv("CYMF_WMF_BLOCKED")) h->blocked = atoi(e7);
     if (const char *e8 = getenv("CYMF_WMF_ROW_ORDER")) h->row_order = atoi(e8);
-    if (const char *e9 = getenv("CYMF_WMF_PIPE64")) h->pipe64 = atoi(e9);
-    if (const char *e9 = getenv("CYMF_WMF_PIPE64_WAVES")) h->pipe64_waves = std::max(1, atoi(e9));
-    if (const char *e9 = getenv("CYMF_WMF_PIPE64_OCC")) h->pipe64_occ = atoi(e9);
-    if (const char *e9 = getenv("CYMF_WMF_PIPE64_SIDES")) h->pipe64_sides = atoi(e9);
-    if (const char *e9 = getenv("CYMF_WMF_PIPE64_PROBE")) h->pipe64_probe = atoi(e9);
     if (const char *e5 = getenv("CYMF_WMF_FAKE_SHARD")) {
         int r = 0, w = 1;
         if (sscanf(e5, "%d/%d", &r, &w) == 2 && w >= 1 && r >= 0 && r < w) { h->shard_rank = r; h->shard_world = w; }
@@ -2028,15 +1668,6 @@ extern "C" int cymf_wmf_set_data(cymf_wmf *h, const int32_t *indptr, const int32
         });
         h->n_order[side] = (int32_t)order.size();
         CYMF_TRY(h->d_order[side].upload(order.data(), order.size(), h->stream));
-        {
-            std::vector<WmfRowInfo> info;
-            for (int32_t r : order) {
-                const int32_t n = ip[r_lo + r + 1] - ip[r_lo + r];
-                if (n > 0) info.push_back(WmfRowInfo{r, ip[r_lo + r], n, 0});
-            }
-            h->n_rowinfo[side] = (int32_t)info.size();
-            CYMF_TRY(wmf_pipe64_pack(h, side, info, side == 0 ? indices : t_indices));
-        }
         // (segments stay in row order: sorted longest first, the segments of one very long row run together and contend for
         // the atomics on its scratch slot -- measured 3.3 instead of 2.9 ms for the C4 item sweep at K=128)
         h->n_segs[side] = (int32_t)segs.size();
