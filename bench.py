@@ -538,6 +538,9 @@ def secondary_paths(device, scale=1.0):
                                     "traffic": _static_traffic(f"C4_k{Kx}")[0] if scale == 1.0 else None, "traffic_source": _static_traffic(f"C4_k{Kx}")[1],
                                     "flops_note": "SURVEY.md 8d prices the full K x K Gramian (2 K^2 nnz per half-sweep); the kernels form the upper tiles only "
                                                   f"({Kx // 32 * (Kx // 32 + 1) // 2} of {(Kx // 32) ** 2}), so MFMA-executed flops are that fraction of the Gramian term",
+                                    "bound_note": "f32 MFMA and VALU instructions take turns on a SIMD (tools/micro/mfma_valu_mix.hip): the floor is MFMA cycles plus four cycles "
+                                                  "per vector instruction, not the MFMA peak (K=64 row kernel: matrix pipe busy 0.485 + VALU issue busy 0.41 of the cycles, "
+                                                  "profiles/r03_wmf_k64_analysis.md)",
                                     "timing": "device-synchronised wall time per epoch (both half-sweeps, all kernels)"}}
         r = res[64]
         r["k128"] = res[128]
