@@ -35,6 +35,17 @@
 // positive item inside a window to ONE group that walks it in sequence -- C2 at 73 wavefronts: norm of H +7.1 % instead of
 // +1.8 %, 4.2 ms per epoch instead of 3.3: the concurrency that matters is the NEGATIVES', which no bucketing orders): the
 // host sizes Adam's launch at about one percent of an epoch in flight.
+// Also tried (round 3, C2, 30 epochs against the sequential oracle; all removed again):
+//   * the c^ updates expected in flight on a row written as ONE sequential block shared out evenly -- c^ = 1 + in-flight triplets
+//     x the row's share of the epoch's touches, delta = (1 - b1^c^) / c^, step_k = lr (9 delta m + (1 - 9 delta) g_k) / ..., m +=
+//     delta (g_k - m) as an atomic delta, which for c^ = 1 is the reference's update and for c^ concurrent updates leaves the
+//     parameter and m where c^ sequential ones would: norm of H +2.1 / +13.9 / +14.3 / +23 % at 73 / 146 / 292 / 512 wavefronts
+//     (last writer's m: +1.0 / +6.8 / +17.6 / +15.0 %) -- the stale first moment is not what inflates the norm;
+//   * the step of the negative item's row scaled by c^-1/4 (between the sqrt(c) of c normalised steps that are noise and the c of
+//     steps that are signal): within the bars at 512 wavefronts (loss +0.03 %, norms +4 / +3 %, Recall@5 -0.002) and at 292 (norms
+//     -7 / +6 %), 0.5 instead of 2.5 ms per epoch -- but an exponent without a derivation, fitted on one data set: not shipped.
+// What inflates the norm is the NORMALISED step: c triplets that read the same stale row step the same way by lr each, whatever
+// the size of their gradients, where a sequence would see its own overshoot; SGD's and AdaGrad's steps shrink with the gradient.
 #include "bpr_groups.h"
 
 #include <algorithm>
