@@ -74,6 +74,40 @@ class Progress:
             self.bar.close()
 
 
+class EpochChunks:
+    """How many epochs the next call into the library runs.  Every call ends with a device synchronisation and the
+    losses' way back; on a small problem (an ml-1m-sized BPR epoch is 0.3 ms of kernels) that is several times the
+    work.  With a validation evaluator every epoch is its own call (the factors are downloaded after each), and so it is
+    in a sharded job (the cut is timed, and every rank has to make the same number of calls); otherwise
+    the calls double while they stay under `target` seconds, so that a progress bar still moves about every tenth of
+    a second.  The epochs themselves are the same whichever way they are cut (one stream of negatives, one order)."""
+
+    def __init__(self, total, every_epoch, target=0.05, cap=256):
+        self.left, self.every, self.target, self.cap, self.n = int(total), bool(every_epoch), target, cap, 1
+        self._t0 = None
+
+    def _every(self, total):   # (tests: an epoch per call)
+        self.left, self.every, self.target, self.cap, self.n, self._t0 = int(total), True, 0.0, 1, 1, None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        import time
+        now = time.perf_counter()
+        if self._t0 is not None and not self.every and now - self._t0 < self.target:
+            self.n = min(self.n * 2, self.cap)
+        if self.left <= 0:
+            raise StopIteration
+        n = 1 if self.every else min(self.n, self.left)
+        self.left -= n
+        self._t0 = time.perf_counter()
+        return n
+
+    def stop(self):
+        self.left = 0
+
+
 class EarlyStopping:
     """cymf/bpr.pyx:173-183, including its quirks: break needs count > 10; the best snapshot is
     refreshed whenever the validation DCG@5 does not get worse than the best seen."""

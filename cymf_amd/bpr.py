@@ -76,16 +76,21 @@ class BPR(object):
             bar = _host.Progress(num_epochs, verbose)
             width = len(str(num_epochs))
             self.losses = []
-            for epoch in range(num_epochs):
-                self.losses.append(trainer.epochs(1)[0])
-                desc = f"EPOCH={epoch+1:{width}} "
-                if self.valid_evaluator:
-                    trainer.download(self.W, self.H)
-                    valid_dcg = self.valid_evaluator.evaluate(self.W, self.H)["DCG@5"]
-                    if stopper.update(valid_dcg):
-                        break
-                    desc += ", DCG@5=" + str(np.round(valid_dcg, 3))
-                bar.step(desc)
+            epoch = 0
+            chunks = _host.EpochChunks(num_epochs, self.valid_evaluator is not None or comm is not None)
+            for n in chunks:                                     # (one call per epoch only where each epoch is looked at)
+                for loss in trainer.epochs(n):
+                    self.losses.append(loss)
+                    epoch += 1
+                    desc = f"EPOCH={epoch:{width}} "
+                    if self.valid_evaluator:
+                        trainer.download(self.W, self.H)
+                        valid_dcg = self.valid_evaluator.evaluate(self.W, self.H)["DCG@5"]
+                        if stopper.update(valid_dcg):
+                            chunks.stop()
+                            break
+                        desc += ", DCG@5=" + str(np.round(valid_dcg, 3))
+                    bar.step(desc)
             bar.close()
             trainer.download(self.W, self.H)
             self.performed_, self.skipped_ = trainer.stats()

@@ -65,12 +65,15 @@ class GloVe(object):
             width = len(str(num_epochs))
             n = max(n_all, 1)
             self.losses = []
-            for it in range(num_epochs):
-                loss = trainer.epochs(1)[0]
+            it = 0
+            for m in _host.EpochChunks(num_epochs, comm is not None):
+                losses = np.asarray(trainer.epochs(m), dtype=np.float64)
                 if comm is not None:   # the loss of the whole job
-                    loss = float(comm.allreduce(np.array([loss], dtype=np.float32))[0])
-                self.losses.append(loss / n)
-                bar.step(f"ITER={it+1:{width}}, LOSS: {np.round(loss / n, 4):.4f}")   # glove.pyx:158-162
+                    losses = comm.allreduce(losses.astype(np.float32)).astype(np.float64)
+                for loss in losses:
+                    it += 1
+                    self.losses.append(float(loss) / n)
+                    bar.step(f"ITER={it:{width}}, LOSS: {np.round(float(loss) / n, 4):.4f}")   # glove.pyx:158-162
             bar.close()
             trainer.download(self.W, self.bias, _W, _bias)
         finally:

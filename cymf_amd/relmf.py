@@ -57,19 +57,24 @@ class RelMF(object):
             bar = _host.Progress(num_epochs, verbose, ncols=100)
             width = len(str(num_epochs))
             self.losses = []
-            for epoch in range(num_epochs):
-                loss = trainer.epochs(1)[0]
+            epoch = 0
+            chunks = _host.EpochChunks(num_epochs, self.valid_evaluator is not None or comm is not None)
+            for n in chunks:
+                losses = np.asarray(trainer.epochs(n), dtype=np.float64)
                 if comm is not None:   # the loss of the whole job (each rank sums over its users' draws)
-                    loss = float(comm.allreduce(np.array([loss], dtype=np.float32))[0])
-                self.losses.append(loss)
-                desc = f"EPOCH={epoch+1:{width}} "
-                if self.valid_evaluator:
-                    trainer.download(self.W, self.H)
-                    valid_dcg = self.valid_evaluator.evaluate(self.W, self.H)["DCG@5"]
-                    if stopper.update(valid_dcg):
-                        break
-                    desc += ", DCG@5=" + str(np.round(valid_dcg, 3))
-                bar.step(desc)
+                    losses = comm.allreduce(losses.astype(np.float32)).astype(np.float64)
+                for loss in losses:
+                    self.losses.append(float(loss))
+                    epoch += 1
+                    desc = f"EPOCH={epoch:{width}} "
+                    if self.valid_evaluator:
+                        trainer.download(self.W, self.H)
+                        valid_dcg = self.valid_evaluator.evaluate(self.W, self.H)["DCG@5"]
+                        if stopper.update(valid_dcg):
+                            chunks.stop()
+                            break
+                        desc += ", DCG@5=" + str(np.round(valid_dcg, 3))
+                    bar.step(desc)
             bar.close()
             trainer.download(self.W, self.H)
             stopper.finish()

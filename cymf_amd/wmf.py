@@ -44,16 +44,21 @@ class WMF(object):
             stopper = _host.EarlyStopping(self)
             bar = _host.Progress(num_epochs, verbose, ncols=100)
             width = len(str(num_epochs))
-            for epoch in range(num_epochs):
-                trainer.epochs(1)
-                desc = f"EPOCH={epoch+1:{width}} "
-                if self.valid_evaluator:
-                    trainer.download(self.W, self.H)
-                    valid_dcg = self.valid_evaluator.evaluate(self.W, self.H)["DCG@5"]
-                    if stopper.update(valid_dcg):
-                        break
-                    desc += ", DCG@5=" + str(np.round(valid_dcg, 3))
-                bar.step(desc)
+            epoch = 0
+            chunks = _host.EpochChunks(num_epochs, self.valid_evaluator is not None or comm is not None)
+            for n in chunks:
+                trainer.epochs(n)
+                for _ in range(n):
+                    epoch += 1
+                    desc = f"EPOCH={epoch:{width}} "
+                    if self.valid_evaluator:
+                        trainer.download(self.W, self.H)
+                        valid_dcg = self.valid_evaluator.evaluate(self.W, self.H)["DCG@5"]
+                        if stopper.update(valid_dcg):
+                            chunks.stop()
+                            break
+                        desc += ", DCG@5=" + str(np.round(valid_dcg, 3))
+                    bar.step(desc)
             bar.close()
             trainer.download(self.W, self.H)
             stopper.finish()

@@ -420,3 +420,19 @@ def test_any_num_components_throughput_mode():
     assert mt.performed_ + mt.skipped_ == 6 * X.nnz
     np.testing.assert_allclose(mt.losses[-2:], losses[-2:], rtol=5e-2)
     assert abs(np.linalg.norm(mt.W) / np.linalg.norm(W) - 1) < 0.1 and abs(np.linalg.norm(mt.H) / np.linalg.norm(H) - 1) < 0.1
+
+
+@pytest.mark.parametrize("opt,lr", [("sgd", 0.05), ("adam", 0.002)])
+def test_fit_is_the_same_however_its_epochs_are_cut_into_calls(opt, lr, monkeypatch):
+    """fit() hands the library several epochs per call while the calls are short (cymf_amd._host.EpochChunks): the result is the
+    one of an epoch per call (cymf/bpr.pyx:160-171's loop), bit for bit in the exact mode -- one stream of negatives, one order."""
+    from cymf_amd import _host
+    X = synthetic.implicit_matrix(300, 500, 4500, 4)
+    cut = _fit(X, 16, opt, lr, 0.01, 11, "float64")
+    assert len(cut.losses) == 11
+    monkeypatch.setattr(_host.EpochChunks, "__init__",
+                        lambda self, total, every_epoch, target=0.05, cap=256: _host.EpochChunks.__dict__["_every"](self, total))
+    whole = _fit(X, 16, opt, lr, 0.01, 11, "float64")
+    assert np.array_equal(cut.W, whole.W) and np.array_equal(cut.H, whole.H)
+    # (the epoch's loss is a sum that the wavefronts add up with double atomics, in the order they finish: equal to rounding)
+    assert np.allclose(np.asarray(cut.losses), np.asarray(whole.losses), rtol=1e-12, atol=0.0)

@@ -352,3 +352,26 @@ def test_micro_benchmarks_cross_compile(tmp_path):
         out = str(tmp_path / (os.path.basename(src) + ".o"))
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", out],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def test_epoch_chunks_cover_the_epochs_and_grow_only_while_calls_are_short():
+    """cymf_amd._host.EpochChunks (the fit() drivers): the calls add up to num_epochs; every epoch is its own call where each one
+    is looked at; otherwise the calls double while they return quickly and stop growing once one takes longer than the target."""
+    import time
+    from cymf_amd import _host
+    assert list(_host.EpochChunks(5, True)) == [1, 1, 1, 1, 1]
+    assert list(_host.EpochChunks(0, False)) == []
+    fast = list(_host.EpochChunks(100, False, target=10.0, cap=16))          # every call "returns at once"
+    assert sum(fast) == 100 and fast[:5] == [1, 2, 4, 8, 16] and max(fast) == 16
+    slow = []
+    for n in _host.EpochChunks(6, False, target=0.0):                        # no call is ever short enough
+        slow.append(n)
+        time.sleep(0.001)
+    assert slow == [1] * 6
+    c = _host.EpochChunks(50, False, target=10.0)
+    got = []
+    for n in c:
+        got.append(n)
+        if len(got) == 3:
+            c.stop()                                                         # early stopping
+    assert got == [1, 2, 4]
