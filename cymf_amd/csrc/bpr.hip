@@ -780,6 +780,8 @@ struct cymf_bpr {
 
     // exact mode scratch
     uint32_t *h_draws2[2] = {nullptr, nullptr};   // pinned (hipHostMalloc): the exact mode reads the epoch's draws on the host
+    PinnedBuf<int32_t> p_tu, p_ti, p_tj;          // ... and writes the epoch's schedule (performed triplets and their turns) for the device
+    PinnedBuf<uint32_t> p_ku, p_ki, p_kj;
     int64_t h_draws_cap[2] = {0, 0};
     int64_t exact_fetched = 0;
     hipEvent_t ev_draws_host[2] = {nullptr, nullptr};
@@ -1077,11 +1079,13 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
         // turns (host): triplet l is access number ku of W[u], ki of H[i], kj of H[j] in sequential order
         std::vector<uint32_t> cntW((size_t)h->U, 0u), cntH((size_t)h->I, 0u);
         h->h_last_neg.assign((size_t)N, -1);
-        std::vector<int32_t> tu, ti, tj;
-        std::vector<uint32_t> ku, ki, kj;
+        // (pinned staging, reused every epoch: the previous epoch's copies were consumed before its kernel ran, and the kernel was waited for)
+        CYMF_TRY(h->p_tu.reserve((size_t)N)); CYMF_TRY(h->p_ti.reserve((size_t)N)); CYMF_TRY(h->p_tj.reserve((size_t)N));
+        CYMF_TRY(h->p_ku.reserve((size_t)N)); CYMF_TRY(h->p_ki.reserve((size_t)N)); CYMF_TRY(h->p_kj.reserve((size_t)N));
+        int32_t *const tu = h->p_tu.p, *const ti = h->p_ti.p, *const tj = h->p_tj.p;
+        uint32_t *const ku = h->p_ku.p, *const ki = h->p_ki.p, *const kj = h->p_kj.p;
         struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } keep_sources_alive{h->stream};   // also on error returns
-        tu.reserve((size_t)N); ti.reserve((size_t)N); tj.reserve((size_t)N);
-        ku.reserve((size_t)N); ki.reserve((size_t)N); kj.reserve((size_t)N);
+        int64_t n_perf = 0;
         for (int64_t l = 0; l < N; ++l) {
             const int32_t u = h->h_users[l], i = h->h_pos_items[l];
             const int32_t j = (int32_t)h_draws[h->h_gpos[l]];
@@ -1089,17 +1093,23 @@ int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
                                                         : (h->h_pos_bits[((size_t)u * h->I + j) >> 6] >> (((size_t)u * h->I + j) & 63)) & 1;
             if (positive) continue;                                    // bpr.pyx:166-167
             h->h_last_neg[l] = j;
-            tu.push_back(u); ti.push_back(i); tj.push_back(j);
-            ku.push_back(cntW[u]++); ki.push_back(cntH[i]++); kj.push_back(cntH[j]++);
+            tu[n_perf] = u; ti[n_perf] = i; tj[n_perf] = j;
+            ku[n_perf] = cntW[u]++; ki[n_perf] = cntH[i]++; kj[n_perf] = cntH[j]++;
+            ++n_perf;
         }
-        const int64_t n_perf = (int64_t)tu.size(), n_skipped = N - n_perf;
+        const int64_t n_skipped = N - n_perf;
         const double t_turns = now();
-        CYMF_TRY(h->d_tu.upload_into_async(tu.data(), tu.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
-        CYMF_TRY(h->d_ti.upload_into_async(ti.data(), ti.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
-        CYMF_TRY(h->d_tj.upload_into_async(tj.data(), tj.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
-        CYMF_TRY(h->d_ku.upload_into_async(ku.data(), ku.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
-        CYMF_TRY(h->d_ki.upload_into_async(ki.data(), ki.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
-        CYMF_TRY(h->d_kj.upload_into_async(kj.data(), kj.size(), (size_t)N, h->stream));   // vectors outlive fetch_loss's sync below
+        CYMF_TRY(h->d_tu.reserve((size_t)N)); CYMF_TRY(h->d_ti.reserve((size_t)N)); CYMF_TRY(h->d_tj.reserve((size_t)N));
+        CYMF_TRY(h->d_ku.reserve((size_t)N)); CYMF_TRY(h->d_ki.reserve((size_t)N)); CYMF_TRY(h->d_kj.reserve((size_t)N));
+        if (n_perf > 0) {
+            const size_t bytes = (size_t)n_perf * sizeof(int32_t);
+            CYMF_HIP(hipMemcpyAsync(h->d_tu.p, tu, bytes, hipMemcpyHostToDevice, h->stream));
+            CYMF_HIP(hipMemcpyAsync(h->d_ti.p, ti, bytes, hipMemcpyHostToDevice, h->stream));
+            CYMF_HIP(hipMemcpyAsync(h->d_tj.p, tj, bytes, hipMemcpyHostToDevice, h->stream));
+            CYMF_HIP(hipMemcpyAsync(h->d_ku.p, ku, bytes, hipMemcpyHostToDevice, h->stream));
+            CYMF_HIP(hipMemcpyAsync(h->d_ki.p, ki, bytes, hipMemcpyHostToDevice, h->stream));
+            CYMF_HIP(hipMemcpyAsync(h->d_kj.p, kj, bytes, hipMemcpyHostToDevice, h->stream));
+        }
         CYMF_TRY(h->d_done.alloc((size_t)h->U + (size_t)h->I));
         CYMF_TRY(h->d_done.zero(h->stream));
         CYMF_TRY(h->d_err.alloc(1));

@@ -114,6 +114,36 @@ struct DevBuf {
     }
 };
 
+// Pinned host staging (hipHostMalloc).  A hipMemcpyAsync FROM PAGEABLE memory is not asynchronous -- the runtime stages it and waits, and
+// that wait was measured at 10-21 ms per epoch of 11 MB of schedule arrays on the test boxes (quantised in ~10.5 ms steps: a blocked wait on a
+// timer tick, not the copy), where the same bytes from pinned memory are enqueued in microseconds and move at PCIe speed.
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { release(); }
+    void release() {
+        if (p && !process_exiting()) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int reserve(size_t count) {
+        if (p && n >= count) return 0;
+        release();
+        if (count == 0) return 0;
+        hipError_t e = hipHostMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(CYMF_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        }
+        n = count;
+        return 0;
+    }
+};
+
 // A side stream: lowest priority.  Not for the scheduling order but for the HARDWARE QUEUES: the runtime deals a process's
 // streams onto a handful of hardware queues, and two streams that land on one queue run strictly one after the other -- the
 // "hidden" side work then sits between the main stream's kernels (measured: rocprofv3 kernel trace of the eight-rank BPR

@@ -971,14 +971,18 @@ struct TicketState {
 
 // turn numbers: sample s is access ka[s] of row a[s] and access kb[s] of row b[s] in sequential order
 template <typename IndexA, typename IndexB>
-void number_turns(int64_t n, IndexA a_of, IndexB b_of, int64_t nA, int64_t nB, std::vector<uint32_t> &ka, std::vector<uint32_t> &kb) {
+void number_turns(int64_t n, IndexA a_of, IndexB b_of, int64_t nA, int64_t nB, uint32_t *ka, uint32_t *kb) {
     std::vector<uint32_t> cA((size_t)nA, 0u), cB((size_t)nB, 0u);
-    ka.resize((size_t)n);
-    kb.resize((size_t)n);
     for (int64_t s = 0; s < n; ++s) {
         ka[(size_t)s] = cA[(size_t)a_of(s)]++;
         kb[(size_t)s] = cB[(size_t)b_of(s)]++;
     }
+}
+template <typename IndexA, typename IndexB>
+void number_turns(int64_t n, IndexA a_of, IndexB b_of, int64_t nA, int64_t nB, std::vector<uint32_t> &ka, std::vector<uint32_t> &kb) {
+    ka.resize((size_t)n);
+    kb.resize((size_t)n);
+    number_turns(n, a_of, b_of, nA, nB, ka.data(), kb.data());
 }
 
 template <typename T>
@@ -1091,6 +1095,7 @@ struct cymf_relmf {
     DevBuf<double> d_loss;
     DevBuf<int> d_err;
     std::vector<uint32_t> h_cells;
+    PinnedBuf<uint32_t> p_cells, p_ka, p_kb;   // exact mode, dataflow launch: the epoch's draws on the host and their turn numbers (pinned staging)
     TicketState ticket;                 // exact mode: dataflow execution (CYMF_RELMF_EXACT_LEVELS=1: one launch per level)
     bool have_data = false, have_params = false;
 };
@@ -1266,20 +1271,22 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
         }
         CYMF_HIP(hipGetLastError());
     } else {
-        h->h_cells.resize((size_t)N);
-        CYMF_HIP(hipMemcpyAsync(h->h_cells.data(), h->d_cells.p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        CYMF_HIP(hipStreamSynchronize(h->stream));
         const char *lv_env = getenv("CYMF_RELMF_EXACT_LEVELS");   // (read per epoch: the tests switch it inside one process)
         const bool by_levels = lv_env && lv_env[0] == '1';
         if (!by_levels && h->K <= 256 && !h->force_wide_cells) {
-            // the epoch's draws in their own order, as ONE dataflow launch (relmf_ticket_kernel): the host only numbers the accesses
-            std::vector<uint32_t> ku, ki;
+            // the epoch's draws in their own order, as ONE dataflow launch (relmf_ticket_kernel): the host only numbers the accesses.
+            // Draws down and turn numbers up through PINNED memory (common.h: PinnedBuf -- the pageable copies were most of the epoch).
+            CYMF_TRY(h->p_cells.reserve((size_t)N)); CYMF_TRY(h->p_ka.reserve((size_t)N)); CYMF_TRY(h->p_kb.reserve((size_t)N));
+            CYMF_HIP(hipMemcpyAsync(h->p_cells.p, h->d_cells.p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            CYMF_HIP(hipStreamSynchronize(h->stream));
             const uint32_t I32 = (uint32_t)h->I;
-            number_turns(N, [&](int64_t s) { return h->h_cells[(size_t)s] / I32; }, [&](int64_t s) { return h->h_cells[(size_t)s] % I32; },
-                         h->U, h->I, ku, ki);
+            const uint32_t *cells = h->p_cells.p;
+            number_turns(N, [&](int64_t s) { return cells[(size_t)s] / I32; }, [&](int64_t s) { return cells[(size_t)s] % I32; },
+                         h->U, h->I, h->p_ka.p, h->p_kb.p);
             CYMF_TRY(h->ticket.prepare(h->U, h->I, h->device, h->stream));
-            CYMF_TRY(h->ticket.ka.upload(ku.data(), ku.size(), h->stream));
-            CYMF_TRY(h->ticket.kb.upload(ki.data(), ki.size(), h->stream));
+            CYMF_TRY(h->ticket.ka.reserve((size_t)N)); CYMF_TRY(h->ticket.kb.reserve((size_t)N));
+            CYMF_HIP(hipMemcpyAsync(h->ticket.ka.p, h->p_ka.p, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            CYMF_HIP(hipMemcpyAsync(h->ticket.kb.p, h->p_kb.p, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
             launch_relmf_ticket<T>(h->K, h->opt, d, h->d_cells.p, N, h->ticket, h->U, h->d_loss.p, h->stream);
             CYMF_HIP(hipGetLastError());
             CYMF_TRY(h->ticket.check(h->stream, "relmf exact mode"));
@@ -1289,6 +1296,9 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
             if (loss_out) *loss_out = loss_t;
             return 0;
         }
+        h->h_cells.resize((size_t)N);
+        CYMF_HIP(hipMemcpyAsync(h->h_cells.data(), h->d_cells.p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        CYMF_HIP(hipStreamSynchronize(h->stream));
         std::vector<int32_t> su((size_t)N), si((size_t)N);
         for (int64_t s = 0; s < N; ++s) {
             su[s] = (int32_t)(h->h_cells[s] / (uint32_t)h->I);
