@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 SO = os.path.join(HERE, "libcymf_hip.so")
 SOURCES = ["core.hip", "rng.hip", "bpr.hip", "bpr_groups.hip", "sgd_models.hip", "relmf_tiles.hip", "wmf.hip", "comm.hip", "eval.hip", "expomf.hip"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-pthread", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():
@@ -55,7 +55,7 @@ def build(force=False, verbose=True):
         if verbose:
             print("[cymf_amd.build] link libcymf_hip.so", flush=True)
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs +
-                              ["-o", SO, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+                              ["-o", SO, "-pthread", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     return SO
 
 

@@ -762,6 +762,7 @@ struct cymf_bpr {
     // data
     int64_t N = 0, N_global = 0;
     std::vector<int32_t> h_users, h_pos_items, h_indptr, h_indices;
+    bool gpos_identity = true;            // h_gpos[l] == l (no global_pos given: one rank)
     std::vector<uint32_t> h_gpos;
     DevBuf<int32_t> d_indptr, d_indices;
     DevBuf<unsigned long long> d_pair_table;   // throughput: open-addressing set of the (user, item) pairs of X
@@ -1557,6 +1558,10 @@ int32_t choose_steps_per_epoch(const cymf_bpr *h, int64_t hottest_item_count) {
 }
 
 int build_throughput_layout(cymf_bpr *h) {
+    static const bool dbg_t = getenv("CYMF_DEBUG_TIMING") != nullptr;   // host-side phases to stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (dbg_t) { const double t = now(); fprintf(stderr, "[layout] %s %.0f ms\n", what, t - t_prev); t_prev = t; } };
     const int64_t N = h->N;
     if (h->steps_auto) {
         std::vector<int64_t> c((size_t)h->I, 0);
@@ -1565,42 +1570,100 @@ int build_throughput_layout(cymf_bpr *h) {
         for (int64_t v : c) mx = std::max(mx, v);
         h->steps_per_epoch = choose_steps_per_epoch(h, mx);
     }
+    lap("steps_per_epoch");
     const int32_t S = h->steps_per_epoch;
-    // step of a triplet = window of the GLOBAL order it falls into; slots sorted by (step, item)
-    auto step_of = [&](int64_t l) -> int32_t {
-        return (int32_t)(((__int128)h->h_gpos[l] * S) / (h->N_global > 0 ? h->N_global : 1));
+    // step of a triplet = window of the GLOBAL order it falls into, floor(g S / N_global) -- by the windows' first positions, not by a
+    // 128-bit division per triplet; slots sorted by (step, item), triplets of one item in their given order.
+    // (10^8 triplets: the passes below are two counting sorts run on a few host threads -- per-thread histograms, offsets by
+    // (bucket, thread), scatter -- which produce exactly the serial order; one thread took 3.4 s here, the scatter's cache misses.)
+    const int64_t Ng = h->N_global > 0 ? h->N_global : 1;
+    std::vector<int64_t> bound((size_t)S + 2);
+    for (int32_t v = 0; v <= S; ++v) bound[(size_t)v] = (int64_t)(((__int128)v * Ng + S - 1) / S);   // first position of window v
+    bound[(size_t)S + 1] = INT64_MAX;
+    const double inv = (double)S / (double)Ng;
+    auto step_of_pos = [&](int64_t g) -> int32_t {
+        int32_t v = (int32_t)((double)g * inv);
+        v = v < 0 ? 0 : (v > S - 1 ? S - 1 : v);
+        while (g < bound[(size_t)v]) --v;
+        while (v + 1 < S && g >= bound[(size_t)v + 1]) ++v;
+        return v;
     };
-    std::vector<int64_t> cnt((size_t)h->I + 1, 0);
-    for (int64_t l = 0; l < N; ++l) cnt[(size_t)h->h_pos_items[l] + 1]++;
-    for (int32_t i = 0; i < h->I; ++i) cnt[i + 1] += cnt[i];
+    const int32_t *const pos_items = h->h_pos_items.data();
+    const int32_t *const users_l = h->h_users.data();
+    const uint32_t *const gpos = h->h_gpos.data();
+    const int32_t I = h->I;
+    int T = host_threads(N);
+    if ((int64_t)T * I > ((int64_t)32 << 20)) T = (int)std::max<int64_t>(1, ((int64_t)32 << 20) / std::max(I, 1));
+    // ---- by item: counting sort of the triplets by positive item
+    std::vector<uint32_t> hist((size_t)T * (size_t)I, 0u);
+    parallel_chunks(N, T, [&](int t, int64_t b, int64_t e) {
+        uint32_t *hs = hist.data() + (size_t)t * I;
+        for (int64_t l = b; l < e; ++l) hs[pos_items[l]]++;
+    });
+    std::vector<int64_t> cnt((size_t)I + 1, 0);   // cnt[i]: first place of item i in the by-item order
+    for (int32_t i = 0; i < I; ++i) {
+        int64_t n_i = 0;
+        for (int t = 0; t < T; ++t) { const uint32_t c = hist[(size_t)t * I + i]; hist[(size_t)t * I + i] = (uint32_t)n_i; n_i += c; }   // -> offset of thread t inside the bucket
+        cnt[(size_t)i + 1] = cnt[(size_t)i] + n_i;
+    }
     {
         int64_t mx = 0;
-        for (int32_t i = 0; i < h->I; ++i) mx = std::max(mx, cnt[i + 1] - cnt[i]);
+        for (int32_t i = 0; i < I; ++i) mx = std::max(mx, cnt[(size_t)i + 1] - cnt[(size_t)i]);
         h->f_item_max = N > 0 ? (double)mx / (double)N : 0.0;
     }
-    {   // hot items: at least hot_threshold positives per step (cnt[] holds the bucket ends here)
-        std::vector<uint32_t> bits(((size_t)h->I + 31) / 32, 0u);
-        int64_t prev = 0;
-        for (int32_t i = 0; i < h->I; ++i) {
-            const int64_t n_i = cnt[i + 1] - prev;
-            prev = cnt[i + 1];
-            if (n_i >= (int64_t)h->hot_threshold * S) bits[i >> 5] |= 1u << (i & 31);
-        }
+    {   // hot items: at least hot_threshold positives per step
+        std::vector<uint32_t> bits(((size_t)I + 31) / 32, 0u);
+        for (int32_t i = 0; i < I; ++i)
+            if (cnt[(size_t)i + 1] - cnt[(size_t)i] >= (int64_t)h->hot_threshold * S) bits[i >> 5] |= 1u << (i & 31);
         CYMF_TRY(h->d_hot_bits.upload(bits.data(), bits.size(), h->stream));
     }
+    lap("item counts, hot bits");
     std::vector<uint32_t> by_item((size_t)N);
-    for (int64_t l = 0; l < N; ++l) by_item[(size_t)cnt[h->h_pos_items[l]]++] = (uint32_t)l;
+    parallel_chunks(N, T, [&](int t, int64_t b, int64_t e) {
+        uint32_t *hs = hist.data() + (size_t)t * I;
+        for (int64_t l = b; l < e; ++l) {
+            const int32_t i = pos_items[l];
+            by_item[(size_t)(cnt[(size_t)i] + hs[i]++)] = (uint32_t)l;
+        }
+    });
+    { std::vector<uint32_t>().swap(hist); }
+    lap("by_item");
+    // ---- by (step, item): counting sort of the by-item order by window
+    const int T2 = host_threads(N);
+    const bool ident = h->gpos_identity;                      // one rank: triplet l is position l of the global order (no gather of it)
+    std::vector<uint16_t> stepq(S <= 65535 ? (size_t)N : 0);  // the window of every place of the by-item order, found once
+    std::vector<int64_t> shist((size_t)T2 * (size_t)S, 0);
+    parallel_chunks(N, T2, [&](int t, int64_t b, int64_t e) {
+        int64_t *hs = shist.data() + (size_t)t * S;
+        for (int64_t q = b; q < e; ++q) {
+            const uint32_t l = by_item[(size_t)q];
+            const int32_t v = step_of_pos(ident ? (int64_t)l : (int64_t)gpos[l]);
+            if (!stepq.empty()) stepq[(size_t)q] = (uint16_t)v;
+            hs[v]++;
+        }
+    });
     h->step_off.assign((size_t)S + 1, 0);
-    for (int64_t l = 0; l < N; ++l) h->step_off[(size_t)step_of(l) + 1]++;
-    for (int32_t s = 0; s < S; ++s) h->step_off[s + 1] += h->step_off[s];
-    std::vector<int64_t> cur(h->step_off.begin(), h->step_off.end() - 1);
+    for (int32_t v = 0; v < S; ++v) {
+        int64_t n_v = 0;
+        for (int t = 0; t < T2; ++t) { const int64_t c = shist[(size_t)t * S + v]; shist[(size_t)t * S + v] = n_v; n_v += c; }
+        h->step_off[(size_t)v + 1] = h->step_off[(size_t)v] + n_v;
+    }
+    lap("step offsets");
     std::vector<int32_t> su((size_t)N), si((size_t)N);
     std::vector<uint32_t> sp((size_t)N), sl((size_t)N);
-    for (int64_t q = 0; q < N; ++q) {   // stable: item order inside each step
-        const uint32_t l = by_item[q];
-        const int64_t p = cur[step_of(l)]++;
-        su[p] = h->h_users[l]; si[p] = h->h_pos_items[l]; sp[p] = h->h_gpos[l]; sl[p] = l;
-    }
+    parallel_chunks(N, T2, [&](int t, int64_t b, int64_t e) {
+        std::vector<int64_t> cur((size_t)S);
+        for (int32_t v = 0; v < S; ++v) cur[(size_t)v] = h->step_off[(size_t)v] + shist[(size_t)t * S + v];
+        int32_t item = (int32_t)(std::upper_bound(cnt.begin(), cnt.end(), b) - cnt.begin()) - 1;   // the bucket place b lies in
+        for (int64_t q = b; q < e; ++q) {   // stable: item order inside each step
+            while (q >= cnt[(size_t)item + 1]) ++item;
+            const uint32_t l = by_item[(size_t)q];
+            const uint32_t g = ident ? l : gpos[l];
+            const int64_t p = cur[stepq.empty() ? (size_t)step_of_pos((int64_t)g) : (size_t)stepq[(size_t)q]]++;
+            su[(size_t)p] = users_l[l]; si[(size_t)p] = item; sp[(size_t)p] = g; sl[(size_t)p] = l;
+        }
+    });
+    lap("slot arrays");
     CYMF_TRY(h->d_slot_user.upload(su.data(), su.size(), h->stream));
     CYMF_TRY(h->d_slot_item.upload(si.data(), si.size(), h->stream));
     if (h->item_aligned && h->opt != CYMF_OPT_SGD) h->h_slot_item = si;
@@ -1608,6 +1671,7 @@ int build_throughput_layout(cymf_bpr *h) {
     h->wave_ranges_for = -1;
     CYMF_TRY(h->d_slot_pos.upload(sp.data(), sp.size(), h->stream));
     CYMF_TRY(h->d_slot_local.upload(sl.data(), sl.size(), h->stream));
+    lap("uploads");
     {   // membership table over the CSR pattern (device build, a few ms)
         const int64_t nnz = (int64_t)h->h_indices.size();
         unsigned long long cap = 1024;
@@ -1626,6 +1690,7 @@ int build_throughput_layout(cymf_bpr *h) {
     CYMF_TRY(h->d_performed.alloc(1));
     CYMF_TRY(h->d_performed.zero(h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
+    lap("pair table, buffers");
     return 0;
 }
 
@@ -1735,6 +1800,10 @@ extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_
     if (!h || N < 0 || (N > 0 && (!users || !positives)) || !indptr)
         return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: bad arguments");
     CYMF_TRY(use_device(h->device));
+    static const bool dbg_t = getenv("CYMF_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (dbg_t) { const double t = now(); fprintf(stderr, "[set_data] %s %.0f ms\n", what, t - t_prev); t_prev = t; } };
     if (!global_pos) N_global = N;
     if (N_global < N || N_global >= (int64_t)0xffffffffll)
         return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: N_global=%lld must be in [N, 2^32-1)", (long long)N_global);
@@ -1755,16 +1824,19 @@ extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_
         if (global_pos && (global_pos[l] < 0 || global_pos[l] >= N_global))
             return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: global_pos[%lld] out of range", (long long)l);
     }
+    lap("validation");
     h->N = N; h->N_global = N_global;
     h->h_users.assign(users, users + N);
     h->h_pos_items.assign(positives, positives + N);
     h->h_gpos.resize((size_t)N);
+    h->gpos_identity = global_pos == nullptr;
     for (int64_t l = 0; l < N; ++l) h->h_gpos[l] = (uint32_t)(global_pos ? global_pos[l] : l);
     h->h_indptr.assign(indptr, indptr + h->U + 1);
     h->h_indices.assign(indices, indices + nnz);
     CYMF_TRY(h->d_indptr.upload(h->h_indptr.data(), h->h_indptr.size(), h->stream));
     CYMF_TRY(h->d_indices.upload(h->h_indices.data(), h->h_indices.size(), h->stream));
     CYMF_HIP(hipStreamSynchronize(h->stream));
+    lap("host copies, CSR upload");
     if (!h->rng_ready) {   // ONE generator for the whole fit (bpr.pyx:141)
         // >= 2M draws per epoch: chunked jump-ahead generator (rng.hip).  Smaller epochs: the lock-free mode generates several
         // epochs per call with that generator (request_epoch_draws); the exact mode, whose epochs take milliseconds of
@@ -1780,7 +1852,9 @@ extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_
         CYMF_TRY(h->rng.init(h->seed, (uint64_t)h->I, h->draw_batch > 1 ? h->gen_stream : h->rng_stream, /*parallel=*/big || h->draw_batch > 1));
         h->rng_ready = true;
     }
+    lap("generator");
     if (h->mode == CYMF_MODE_THROUGHPUT) CYMF_TRY(build_throughput_layout(h));
+    lap("layout (total)");
     h->h_pos_bits.clear();
     if (h->mode == CYMF_MODE_EXACT && (uint64_t)h->U * (uint64_t)h->I <= (1ull << 31)) {   // user_positives (bpr.pyx:146-147) as a bitmap
         h->h_pos_bits.assign((size_t)(((uint64_t)h->U * h->I + 63) >> 6), 0ull);

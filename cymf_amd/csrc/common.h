@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cymf_amd.h"
@@ -113,6 +114,26 @@ struct DevBuf {
         return 0;
     }
 };
+
+// Host loops over the triplets of a large problem (set_data: bucketing 10^8 interactions) on a few threads: f(t, begin, end) for the
+// t-th of T contiguous chunks of [0, n), T = host_threads(n) <= 16 (CYMF_HOST_THREADS), the caller's thread included.
+inline int host_threads(int64_t n) {
+    static const int avail = [] {
+        const char *e = getenv("CYMF_HOST_THREADS");
+        const int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return v < 1 ? 1 : (v > 16 ? 16 : v);
+    }();
+    return n < ((int64_t)1 << 20) ? 1 : avail;
+}
+template <typename F>
+void parallel_chunks(int64_t n, int T, F f) {
+    if (T <= 1 || n <= 0) { f(0, (int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)T - 1);
+    for (int t = 1; t < T; ++t) pool.emplace_back([&, t] { f(t, n * t / T, n * (t + 1) / T); });
+    f(0, (int64_t)0, n / T);
+    for (auto &th : pool) th.join();
+}
 
 // Pinned host staging (hipHostMalloc).  A hipMemcpyAsync FROM PAGEABLE memory is not asynchronous -- the runtime stages it and waits, and
 // that wait was measured at 10-21 ms per epoch of 11 MB of schedule arrays on the test boxes (quantised in ~10.5 ms steps: a blocked wait on a
