@@ -113,7 +113,7 @@ def test_glove_with_world1_communicator_and_steps():
         m.fit(X, 3, 0, **kw)
         fits[name] = (m.W.copy(), np.array(m.losses))
     # (two lock-free fits of the same data differ by the order their wavefronts finished in: eight repetitions measured epoch losses
-    #  apart by up to 1.3e-3 and norms by up to 3.5e-3 -- the former bar of 2e-3 on the losses failed about one run in five)
+    #  apart by up to 1.3e-3 and norms by up to 3.5e-3; the former bar of 2e-3 on the losses failed once in five runs of the suite)
     np.testing.assert_allclose(fits["comm"][1], fits["plain"][1], rtol=5e-3)
     assert abs(np.linalg.norm(fits["comm"][0]) / np.linalg.norm(fits["plain"][0]) - 1) < 1e-2
     np.testing.assert_allclose(fits["comm3"][1], fits["steps3"][1], rtol=5e-3)
