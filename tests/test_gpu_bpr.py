@@ -436,3 +436,42 @@ def test_fit_is_the_same_however_its_epochs_are_cut_into_calls(opt, lr, monkeypa
     assert np.array_equal(cut.W, whole.W) and np.array_equal(cut.H, whole.H)
     # (the epoch's loss is a sum that the wavefronts add up with double atomics, in the order they finish: equal to rounding)
     assert np.allclose(np.asarray(cut.losses), np.asarray(whole.losses), rtol=1e-12, atol=0.0)
+
+
+def test_layout_built_on_several_host_threads_applies_every_triplet_once():
+    """cymf_bpr_set_data buckets a large problem on several host threads (two counting sorts, csrc/bpr.hip: from 2^20 triplets up).
+    1.2 M users with ONE triplet each over a skewed item set: to first order in lr (weight decay 0) a user's row moves by
+    lr sigmoid(-x0) (H0[i] - H0[j]) whatever else happens, exactly once -- which pins user, positive item, stream position and
+    negative of every slot of the threaded layout; the negatives are the stream's, bit for bit, in the given order."""
+    U, I, K, lr = 1_200_000, 50_000, 8, 1e-4   # (lr small: the hottest item's row, 10^5 updates, must not drift by more than a few per cent)
+    rs = np.random.RandomState(11)
+    items = np.minimum((rs.pareto(1.2, U) * 40).astype(np.int64), I - 1).astype(np.int32)   # a few very popular items, a long tail
+    users = rs.permutation(U).astype(np.int32)                                              # the given order: users shuffled
+    pos = items[users]
+    indptr = np.arange(U + 1, dtype=np.int32)
+    W0, H0 = oracle.reference_init(U, I, K)
+    W0, H0 = W0.astype(np.float32).astype(np.float64), H0.astype(np.float32).astype(np.float64)
+    t = BprTrainer(U, I, K, "sgd", lr, 0.0, mode="throughput")
+    t.set_data(users, pos, indptr, items)
+    t.upload(W0, H0)
+    t.epochs(1)
+    neg = t.last_negatives()
+    W, H = np.empty_like(W0), np.empty_like(H0)
+    t.download(W, H)
+    performed, skipped = t.stats()
+    t.close()
+    draws = oracle.uniform_stream(1234, I, U)
+    assert np.array_equal(neg, np.where(draws == pos, -1, draws))
+    assert performed == int((neg >= 0).sum()) and performed + skipped == U
+    ok = neg >= 0
+    u, i, j = users[ok], pos[ok], neg[ok]
+    d0 = H0[i] - H0[j]
+    x0 = np.einsum("nk,nk->n", W0[u], d0)
+    pred = (lr / (1.0 + np.exp(x0)))[:, None] * d0
+    got = (W - W0)[u]
+    # the item rows drift by O(lr) while the epoch runs (a hot row by many updates): the prediction holds to a few per cent of
+    # the largest component; a slot applied twice, not at all, or with a wrong row would be off by 100 % or more
+    ref = np.abs(pred).max(axis=1)
+    err = np.abs(got - pred).max(axis=1)
+    assert (err <= 0.05 * ref + 1e-9).mean() > 0.999 and (err <= 0.5 * ref + 1e-9).all()
+    assert np.array_equal((W - W0)[users[~ok]], np.zeros(((~ok).sum(), K)))
