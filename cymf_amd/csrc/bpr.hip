@@ -781,8 +781,15 @@ struct cymf_bpr {
 
     // exact mode scratch
     uint32_t *h_draws2[2] = {nullptr, nullptr};   // pinned (hipHostMalloc): the exact mode reads the epoch's draws on the host
-    PinnedBuf<int32_t> p_tu, p_ti, p_tj;          // ... and writes the epoch's schedule (performed triplets and their turns) for the device
-    PinnedBuf<uint32_t> p_ku, p_ki, p_kj;
+    // ... and writes the epoch's schedule (performed triplets and their turns) for the device: two sets, by epoch parity -- the
+    // schedule of epoch e + 1 is numbered and sent up while the dataflow kernel of epoch e runs (exact_prepare)
+    PinnedBuf<int32_t> p_tu[2], p_ti[2], p_tj[2];
+    PinnedBuf<uint32_t> p_ku[2], p_ki[2], p_kj[2];
+    DevBuf<int32_t> d_xu[2], d_xi[2], d_xj[2];
+    DevBuf<uint32_t> d_xku[2], d_xki[2], d_xkj[2];
+    struct ExactPrep { int64_t epoch = -1, n_perf = 0, n_skipped = 0; double t_draws = 0, t_turns = 0; } prep[2];
+    hipStream_t up_stream = nullptr;              // the schedule's uploads (they must not queue behind the running kernel)
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
     int64_t h_draws_cap[2] = {0, 0};
     int64_t exact_fetched = 0;
     hipEvent_t ev_draws_host[2] = {nullptr, nullptr};
@@ -1063,93 +1070,122 @@ int exact_fetch_draws(cymf_bpr *h, int64_t g) {
     return 0;
 }
 
+// Exact mode, dataflow launch, first half (host): wait for the draws of epoch e, number the turns -- triplet l is access number ku
+// of W[u], ki of H[i], kj of H[j] in sequential order -- into the pinned set of e's parity and send them up on up_stream.
+// Runs while the kernel of epoch e - 1 works (cymf_bpr_epochs): that kernel reads the OTHER set.
+int exact_prepare(cymf_bpr *h, int64_t e) {
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const int b = (int)(e & 1);
+    if (h->prep[b].epoch == e) return 0;
+    const double t_entry = now();
+    CYMF_TRY(exact_fetch_draws(h, e));                  // (already on its way since the previous epoch, except the first time)
+    CYMF_HIP(hipEventSynchronize(h->ev_draws_host[b]));
+    const uint32_t *h_draws = h->h_draws2[b];
+    const int64_t N = h->N;
+    const double t_draws = now();
+    std::vector<uint32_t> cntW((size_t)h->U, 0u), cntH((size_t)h->I, 0u);
+    h->h_last_neg.assign((size_t)N, -1);
+    // (pinned staging -- common.h: PinnedBuf -- reused every second epoch: the copies of epoch e - 2 were consumed before its kernel ran)
+    CYMF_TRY(h->p_tu[b].reserve((size_t)N)); CYMF_TRY(h->p_ti[b].reserve((size_t)N)); CYMF_TRY(h->p_tj[b].reserve((size_t)N));
+    CYMF_TRY(h->p_ku[b].reserve((size_t)N)); CYMF_TRY(h->p_ki[b].reserve((size_t)N)); CYMF_TRY(h->p_kj[b].reserve((size_t)N));
+    int32_t *const tu = h->p_tu[b].p, *const ti = h->p_ti[b].p, *const tj = h->p_tj[b].p;
+    uint32_t *const ku = h->p_ku[b].p, *const ki = h->p_ki[b].p, *const kj = h->p_kj[b].p;
+    int64_t n_perf = 0;
+    for (int64_t l = 0; l < N; ++l) {
+        const int32_t u = h->h_users[l], i = h->h_pos_items[l];
+        const int32_t j = (int32_t)h_draws[h->h_gpos[l]];
+        const bool positive = h->h_pos_bits.empty() ? csr_has(h->h_indptr, h->h_indices, u, j)
+                                                    : (h->h_pos_bits[((size_t)u * h->I + j) >> 6] >> (((size_t)u * h->I + j) & 63)) & 1;
+        if (positive) continue;                                    // bpr.pyx:166-167
+        h->h_last_neg[l] = j;
+        tu[n_perf] = u; ti[n_perf] = i; tj[n_perf] = j;
+        ku[n_perf] = cntW[u]++; ki[n_perf] = cntH[i]++; kj[n_perf] = cntH[j]++;
+        ++n_perf;
+    }
+    const double t_turns = now();
+    CYMF_TRY(h->d_xu[b].reserve((size_t)N)); CYMF_TRY(h->d_xi[b].reserve((size_t)N)); CYMF_TRY(h->d_xj[b].reserve((size_t)N));
+    CYMF_TRY(h->d_xku[b].reserve((size_t)N)); CYMF_TRY(h->d_xki[b].reserve((size_t)N)); CYMF_TRY(h->d_xkj[b].reserve((size_t)N));
+    if (n_perf > 0) {
+        const size_t bytes = (size_t)n_perf * sizeof(int32_t);
+        CYMF_HIP(hipMemcpyAsync(h->d_xu[b].p, tu, bytes, hipMemcpyHostToDevice, h->up_stream));
+        CYMF_HIP(hipMemcpyAsync(h->d_xi[b].p, ti, bytes, hipMemcpyHostToDevice, h->up_stream));
+        CYMF_HIP(hipMemcpyAsync(h->d_xj[b].p, tj, bytes, hipMemcpyHostToDevice, h->up_stream));
+        CYMF_HIP(hipMemcpyAsync(h->d_xku[b].p, ku, bytes, hipMemcpyHostToDevice, h->up_stream));
+        CYMF_HIP(hipMemcpyAsync(h->d_xki[b].p, ki, bytes, hipMemcpyHostToDevice, h->up_stream));
+        CYMF_HIP(hipMemcpyAsync(h->d_xkj[b].p, kj, bytes, hipMemcpyHostToDevice, h->up_stream));
+    }
+    CYMF_HIP(hipEventRecord(h->ev_up[b], h->up_stream));
+    h->prep[b].epoch = e; h->prep[b].n_perf = n_perf; h->prep[b].n_skipped = N - n_perf;
+    h->prep[b].t_draws = t_draws - t_entry; h->prep[b].t_turns = t_turns - t_draws;
+    return 0;
+}
+
+// ... second half: the prepared epoch as ONE dataflow launch, its loss read back (synchronises).  `next`: prepare epoch e + 1 under
+// this epoch's kernel.
 template <typename T>
-int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out) {
+int exact_run(cymf_bpr *h, BprStore<T> &st, bool next, double *loss_out) {
     static const bool dbg_t = getenv("CYMF_DEBUG_TIMING") != nullptr;   // host-side phases of an exact epoch to stderr
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const int64_t e = h->epoch_cursor;
+    const int b = (int)(e & 1);
     const double t_entry = now();
+    CYMF_TRY(exact_prepare(h, e));                      // (done under the previous epoch's kernel, except for a call's first epoch)
+    const double t_prep = now();
+    const int64_t N = h->N, n_perf = h->prep[b].n_perf, n_skipped = h->prep[b].n_skipped;
+    struct SyncOnExit { hipStream_t s, u; ~SyncOnExit() { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(u); } } settle{h->stream, h->up_stream};   // also on error returns
+    CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_up[b], 0));
+    CYMF_TRY(h->d_done.alloc((size_t)h->U + (size_t)h->I));
+    CYMF_TRY(h->d_done.zero(h->stream));
+    CYMF_TRY(h->d_err.alloc(1));
+    CYMF_TRY(h->d_err.zero(h->stream));
+    CYMF_TRY(h->d_next.alloc(1));
+    CYMF_TRY(h->d_next.zero(h->stream));
+    CYMF_TRY(h->d_loss.zero(h->stream));
+    BprDev<T> d = st.view(h->K, h->wd, h->lr);
+    hipEvent_t p0 = nullptr, p1 = nullptr;
+    if (h->profiling) {
+        CYMF_HIP(hipEventCreate(&p0)); CYMF_HIP(hipEventCreate(&p1));
+        CYMF_HIP(hipEventRecord(p0, h->stream));
+    }
+    if (n_perf > 0)
+        CYMF_TRY(launch_ticket<T>(h->K, h->opt, d, h->d_xu[b].p, h->d_xi[b].p, h->d_xj[b].p, h->d_xku[b].p, h->d_xki[b].p, h->d_xkj[b].p, n_perf,
+                                  h->d_done.p, h->d_done.p + h->U, h->d_next.p, h->d_loss.p, h->d_err.p, h->n_cu, h->stream));
+    if (h->profiling) {
+        CYMF_HIP(hipEventRecord(p1, h->stream));
+        h->prof_events.emplace_back(p0, p1);
+        h->prof_launches += 1;
+        h->prof_units += n_perf;
+    }
+    // the next epoch's draws are generated and copied to the host now, under this epoch's kernel: a one-workgroup
+    // generator on an otherwise idle GPU runs at idle clocks (measured 20-28 ms instead of 0.8 ms on some boxes)
+    CYMF_TRY(exact_fetch_draws(h, e + 1));
+    const double t_launched = now();
+    if (next) CYMF_TRY(exact_prepare(h, e + 1));        // the host's share of epoch e + 1, under the kernel of epoch e
+    const double t_next = now();
+    int err = 0;
+    CYMF_HIP(hipMemcpyAsync(&err, h->d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    double loss = 0;
+    CYMF_TRY(fetch_loss(h, &loss));
+    if (dbg_t) fprintf(stderr, "[exact] epoch %lld: own schedule %.2f ms (draws %.2f, turns %.2f when it was made), memsets+launch %.2f ms, next epoch's schedule %.2f ms, "
+                               "wait for kernel+readback %.2f ms\n", (long long)e, t_prep - t_entry, h->prep[b].t_draws, h->prep[b].t_turns, t_launched - t_prep,
+                       t_next - t_launched, now() - t_next);
+    if (err) return fail(CYMF_ERR_HIP, "exact mode: a wavefront waited past the spin limit for its turn (inconsistent schedule)");
+    if (loss_out) *loss_out = N ? loss / (double)N : 0.0;   // bpr.pyx:171
+    h->performed += n_perf;
+    h->skipped += n_skipped;
+    h->epoch_cursor++;
+    return 0;
+}
+
+template <typename T>
+int epoch_exact(cymf_bpr *h, BprStore<T> &st, double *loss_out, bool next = false) {
+    if (h->exact_tickets) return exact_run<T>(h, st, next, loss_out);
     const int64_t e = h->epoch_cursor;
     const int b = (int)(e & 1);
     CYMF_TRY(exact_fetch_draws(h, e));                  // (already on its way since the previous epoch, except the first time)
     CYMF_HIP(hipEventSynchronize(h->ev_draws_host[b]));
     const uint32_t *h_draws = h->h_draws2[b];
-
     const int64_t N = h->N;
-    const double t_draws = now();
-    if (h->exact_tickets) {
-        // turns (host): triplet l is access number ku of W[u], ki of H[i], kj of H[j] in sequential order
-        std::vector<uint32_t> cntW((size_t)h->U, 0u), cntH((size_t)h->I, 0u);
-        h->h_last_neg.assign((size_t)N, -1);
-        // (pinned staging, reused every epoch: the previous epoch's copies were consumed before its kernel ran, and the kernel was waited for)
-        CYMF_TRY(h->p_tu.reserve((size_t)N)); CYMF_TRY(h->p_ti.reserve((size_t)N)); CYMF_TRY(h->p_tj.reserve((size_t)N));
-        CYMF_TRY(h->p_ku.reserve((size_t)N)); CYMF_TRY(h->p_ki.reserve((size_t)N)); CYMF_TRY(h->p_kj.reserve((size_t)N));
-        int32_t *const tu = h->p_tu.p, *const ti = h->p_ti.p, *const tj = h->p_tj.p;
-        uint32_t *const ku = h->p_ku.p, *const ki = h->p_ki.p, *const kj = h->p_kj.p;
-        struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } keep_sources_alive{h->stream};   // also on error returns
-        int64_t n_perf = 0;
-        for (int64_t l = 0; l < N; ++l) {
-            const int32_t u = h->h_users[l], i = h->h_pos_items[l];
-            const int32_t j = (int32_t)h_draws[h->h_gpos[l]];
-            const bool positive = h->h_pos_bits.empty() ? csr_has(h->h_indptr, h->h_indices, u, j)
-                                                        : (h->h_pos_bits[((size_t)u * h->I + j) >> 6] >> (((size_t)u * h->I + j) & 63)) & 1;
-            if (positive) continue;                                    // bpr.pyx:166-167
-            h->h_last_neg[l] = j;
-            tu[n_perf] = u; ti[n_perf] = i; tj[n_perf] = j;
-            ku[n_perf] = cntW[u]++; ki[n_perf] = cntH[i]++; kj[n_perf] = cntH[j]++;
-            ++n_perf;
-        }
-        const int64_t n_skipped = N - n_perf;
-        const double t_turns = now();
-        CYMF_TRY(h->d_tu.reserve((size_t)N)); CYMF_TRY(h->d_ti.reserve((size_t)N)); CYMF_TRY(h->d_tj.reserve((size_t)N));
-        CYMF_TRY(h->d_ku.reserve((size_t)N)); CYMF_TRY(h->d_ki.reserve((size_t)N)); CYMF_TRY(h->d_kj.reserve((size_t)N));
-        if (n_perf > 0) {
-            const size_t bytes = (size_t)n_perf * sizeof(int32_t);
-            CYMF_HIP(hipMemcpyAsync(h->d_tu.p, tu, bytes, hipMemcpyHostToDevice, h->stream));
-            CYMF_HIP(hipMemcpyAsync(h->d_ti.p, ti, bytes, hipMemcpyHostToDevice, h->stream));
-            CYMF_HIP(hipMemcpyAsync(h->d_tj.p, tj, bytes, hipMemcpyHostToDevice, h->stream));
-            CYMF_HIP(hipMemcpyAsync(h->d_ku.p, ku, bytes, hipMemcpyHostToDevice, h->stream));
-            CYMF_HIP(hipMemcpyAsync(h->d_ki.p, ki, bytes, hipMemcpyHostToDevice, h->stream));
-            CYMF_HIP(hipMemcpyAsync(h->d_kj.p, kj, bytes, hipMemcpyHostToDevice, h->stream));
-        }
-        CYMF_TRY(h->d_done.alloc((size_t)h->U + (size_t)h->I));
-        CYMF_TRY(h->d_done.zero(h->stream));
-        CYMF_TRY(h->d_err.alloc(1));
-        CYMF_TRY(h->d_err.zero(h->stream));
-        CYMF_TRY(h->d_next.alloc(1));
-        CYMF_TRY(h->d_next.zero(h->stream));
-        CYMF_TRY(h->d_loss.zero(h->stream));
-        BprDev<T> d = st.view(h->K, h->wd, h->lr);
-        hipEvent_t p0 = nullptr, p1 = nullptr;
-        if (h->profiling) {
-            CYMF_HIP(hipEventCreate(&p0)); CYMF_HIP(hipEventCreate(&p1));
-            CYMF_HIP(hipEventRecord(p0, h->stream));
-        }
-        const double t_up = now();
-        if (n_perf > 0)
-            CYMF_TRY(launch_ticket<T>(h->K, h->opt, d, h->d_tu.p, h->d_ti.p, h->d_tj.p, h->d_ku.p, h->d_ki.p, h->d_kj.p, n_perf,
-                                      h->d_done.p, h->d_done.p + h->U, h->d_next.p, h->d_loss.p, h->d_err.p, h->n_cu, h->stream));
-        if (h->profiling) {
-            CYMF_HIP(hipEventRecord(p1, h->stream));
-            h->prof_events.emplace_back(p0, p1);
-            h->prof_launches += 1;
-            h->prof_units += n_perf;
-        }
-        // the next epoch's draws are generated and copied to the host now, under this epoch's kernel: a one-workgroup
-        // generator on an otherwise idle GPU runs at idle clocks (measured 20-28 ms instead of 0.8 ms on some boxes)
-        CYMF_TRY(exact_fetch_draws(h, e + 1));
-        int err = 0;
-        CYMF_HIP(hipMemcpyAsync(&err, h->d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        double loss = 0;
-        CYMF_TRY(fetch_loss(h, &loss));
-        if (dbg_t) fprintf(stderr, "[exact] draws %.2f ms, turns %.2f ms, uploads+memsets %.2f ms, launch+kernel+readback %.2f ms\n",
-                           t_draws - t_entry, t_turns - t_draws, t_up - t_turns, now() - t_up);
-        if (err) return fail(CYMF_ERR_HIP, "exact mode: a wavefront waited past the spin limit for its turn (inconsistent schedule)");
-        if (loss_out) *loss_out = N ? loss / (double)N : 0.0;   // bpr.pyx:171
-        h->performed += n_perf;
-        h->skipped += n_skipped;
-        h->epoch_cursor++;
-        return 0;
-    }
     // level scheduling (host): level(l) = 1 + max(level of the last earlier triplet touching u, i or j)
     std::vector<int32_t> lastW((size_t)h->U, 0), lastH((size_t)h->I, 0), level((size_t)N, 0);
     h->h_last_neg.assign((size_t)N, -1);
@@ -1742,7 +1778,9 @@ extern "C" int cymf_bpr_create(cymf_bpr **out, int32_t U, int32_t I, int32_t K, 
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_epoch_done[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_draws_host[b], hipEventDisableTiming);
+        if (e == hipSuccess && mode == CYMF_MODE_EXACT) e = hipEventCreateWithFlags(&h->ev_up[b], hipEventDisableTiming);
     }
+    if (e == hipSuccess && mode == CYMF_MODE_EXACT) e = hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e)); }
     int rc = h->d_loss.alloc(1);
     if (rc) { delete h; return rc; }
@@ -1825,6 +1863,7 @@ extern "C" int cymf_bpr_set_data(cymf_bpr *h, const int32_t *users, const int32_
             return fail(CYMF_ERR_INVALID, "cymf_bpr_set_data: global_pos[%lld] out of range", (long long)l);
     }
     lap("validation");
+    h->prep[0].epoch = h->prep[1].epoch = -1;   // (exact mode: no schedule made for other data survives)
     h->N = N; h->N_global = N_global;
     h->h_users.assign(users, users + N);
     h->h_pos_items.assign(positives, positives + N);
@@ -1952,8 +1991,9 @@ extern "C" int cymf_bpr_epochs(cymf_bpr *h, int32_t n_epochs, double *loss_out) 
         if (h->comm) return fail(CYMF_ERR_UNSUPPORTED, "exact (sequential-order) mode is single-GPU by definition");
         for (int32_t e = 0; e < n_epochs; ++e) {
             double *lo = loss_out ? loss_out + e : nullptr;
-            if (h->dtype == CYMF_F32) CYMF_TRY(epoch_exact<float>(h, h->f32, lo));
-            else CYMF_TRY(epoch_exact<double>(h, h->f64, lo));
+            const bool next = e + 1 < n_epochs;   // the following epoch's schedule is made under this epoch's kernel
+            if (h->dtype == CYMF_F32) CYMF_TRY(epoch_exact<float>(h, h->f32, lo, next));
+            else CYMF_TRY(epoch_exact<double>(h, h->f64, lo, next));
         }
         return 0;
     }
@@ -2068,6 +2108,8 @@ extern "C" int cymf_bpr_destroy(cymf_bpr *h) {
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->rng_stream) (void)hipStreamDestroy(h->rng_stream);
     for (int b = 0; b < 2; ++b) { if (h->h_draws2[b]) (void)hipHostFree(h->h_draws2[b]); if (h->ev_draws_host[b]) (void)hipEventDestroy(h->ev_draws_host[b]); }
+    if (h->up_stream) { (void)hipStreamSynchronize(h->up_stream); (void)hipStreamDestroy(h->up_stream); }
+    for (int b = 0; b < 2; ++b) if (h->ev_up[b]) (void)hipEventDestroy(h->ev_up[b]);
     delete h;
     return 0;
 }
