@@ -986,8 +986,9 @@ void number_turns(int64_t n, IndexA a_of, IndexB b_of, int64_t nA, int64_t nB, s
 }
 
 template <typename T>
-void launch_relmf_ticket(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, TicketState &t, int32_t U, double *loss, hipStream_t s) {
-#define OPT_(R_, P_, O_) hipLaunchKernelGGL((relmf_ticket_kernel<T, R_, P_, O_>), dim3(t.blocks(n)), dim3(256), 0, s, d, cells, n, t.ka.p, t.kb.p, \
+void launch_relmf_ticket(int K, int opt, const RelDev<T> &d, const uint32_t *cells, int64_t n, TicketState &t, const uint32_t *ka, const uint32_t *kb,
+                         int32_t U, double *loss, hipStream_t s) {
+#define OPT_(R_, P_, O_) hipLaunchKernelGGL((relmf_ticket_kernel<T, R_, P_, O_>), dim3(t.blocks(n)), dim3(256), 0, s, d, cells, n, ka, kb, \
                                             t.done.p, t.done.p + U, t.next.p, loss, t.err.p)
 #define CALL_(R_, P_)                                                                              \
     do {                                                                                           \
@@ -1095,7 +1096,13 @@ struct cymf_relmf {
     DevBuf<double> d_loss;
     DevBuf<int> d_err;
     std::vector<uint32_t> h_cells;
-    PinnedBuf<uint32_t> p_cells, p_ka, p_kb;   // exact mode, dataflow launch: the epoch's draws on the host and their turn numbers (pinned staging)
+    // exact mode: the epoch's draws (device and pinned host copy) and, for the dataflow launch, their turn numbers -- two sets by epoch
+    // parity: epoch e + 1 is drawn, brought down, numbered and sent up on side_stream while the kernel of epoch e runs (relmf_exact_prepare)
+    DevBuf<uint32_t> x_cells[2], x_ka[2], x_kb[2];
+    PinnedBuf<uint32_t> p_cells[2], p_ka[2], p_kb[2];
+    int64_t x_epoch[2] = {-1, -1};
+    bool x_turns[2] = {false, false};
+    hipEvent_t ev_x[2] = {nullptr, nullptr};
     TicketState ticket;                 // exact mode: dataflow execution (CYMF_RELMF_EXACT_LEVELS=1: one launch per level)
     bool have_data = false, have_params = false;
 };
@@ -1155,15 +1162,45 @@ static int relmf_prepare_tiles(cymf_relmf *h, int64_t g_want) {
     return 0;
 }
 
+// Exact mode: the draws of epoch e on the device and (pinned) on the host and, for the dataflow launch, their turn numbers on the
+// device; everything on side_stream, recorded in ev_x[e & 1].  Called for epoch e + 1 while the kernel of epoch e runs.
+static int relmf_exact_prepare(cymf_relmf *h, int64_t e, bool turns) {
+    const int b = (int)(e & 1);
+    const int64_t N = (int64_t)h->U * h->I;
+    hipStream_t ss = h->side_stream;
+    if (h->x_epoch[b] != e) {
+        CYMF_TRY(h->x_cells[b].alloc((size_t)N));
+        CYMF_TRY(h->rng.generate(0, N, h->x_cells[b].p, ss));      // relmf.pyx:128: the epochs' draws in stream order
+        CYMF_TRY(h->p_cells[b].reserve((size_t)N));
+        CYMF_HIP(hipMemcpyAsync(h->p_cells[b].p, h->x_cells[b].p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, ss));
+        CYMF_HIP(hipStreamSynchronize(ss));
+        h->x_epoch[b] = e;
+        h->x_turns[b] = false;
+    }
+    if (turns && !h->x_turns[b]) {
+        CYMF_TRY(h->p_ka[b].reserve((size_t)N)); CYMF_TRY(h->p_kb[b].reserve((size_t)N));
+        const uint32_t I32 = (uint32_t)h->I;
+        const uint32_t *cells = h->p_cells[b].p;
+        number_turns(N, [&](int64_t s) { return cells[(size_t)s] / I32; }, [&](int64_t s) { return cells[(size_t)s] % I32; },
+                     h->U, h->I, h->p_ka[b].p, h->p_kb[b].p);
+        CYMF_TRY(h->x_ka[b].reserve((size_t)N)); CYMF_TRY(h->x_kb[b].reserve((size_t)N));
+        CYMF_HIP(hipMemcpyAsync(h->x_ka[b].p, h->p_ka[b].p, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, ss));
+        CYMF_HIP(hipMemcpyAsync(h->x_kb[b].p, h->p_kb[b].p, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, ss));
+        h->x_turns[b] = true;
+    }
+    CYMF_HIP(hipEventRecord(h->ev_x[b], ss));
+    return 0;
+}
+
 template <typename T>
-static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
+static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out, bool next = false) {
     const int64_t N = (int64_t)h->U * h->I;   // relmf.pyx:120: one epoch = U*I draws with replacement
     const bool tiled = h->mode == CYMF_MODE_THROUGHPUT && h->tile_ok && !h->comm && sizeof(T) == 4;
     const bool stepped = tiled || (h->mode == CYMF_MODE_THROUGHPUT && h->step_path && sizeof(T) == 4);
     if (h->wide && h->mode != CYMF_MODE_THROUGHPUT)
         return fail(CYMF_ERR_UNSUPPORTED, "cymf_relmf: U*I = %lld draws per epoch: the exact (sequential-order) mode schedules the epoch's draws on the "
                     "host and is limited to U*I < 2^32; the lock-free mode takes any size", (long long)N);
-    if (!stepped && !h->wide) {
+    if (!stepped && !h->wide && h->mode != CYMF_MODE_EXACT) {   // (exact mode: relmf_exact_prepare)
         CYMF_TRY(h->d_cells.alloc((size_t)N));
         CYMF_TRY(h->rng.generate(0, N, h->d_cells.p, h->stream));
     }
@@ -1273,22 +1310,18 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
     } else {
         const char *lv_env = getenv("CYMF_RELMF_EXACT_LEVELS");   // (read per epoch: the tests switch it inside one process)
         const bool by_levels = lv_env && lv_env[0] == '1';
-        if (!by_levels && h->K <= 256 && !h->force_wide_cells) {
-            // the epoch's draws in their own order, as ONE dataflow launch (relmf_ticket_kernel): the host only numbers the accesses.
-            // Draws down and turn numbers up through PINNED memory (common.h: PinnedBuf -- the pageable copies were most of the epoch).
-            CYMF_TRY(h->p_cells.reserve((size_t)N)); CYMF_TRY(h->p_ka.reserve((size_t)N)); CYMF_TRY(h->p_kb.reserve((size_t)N));
-            CYMF_HIP(hipMemcpyAsync(h->p_cells.p, h->d_cells.p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-            CYMF_HIP(hipStreamSynchronize(h->stream));
-            const uint32_t I32 = (uint32_t)h->I;
-            const uint32_t *cells = h->p_cells.p;
-            number_turns(N, [&](int64_t s) { return cells[(size_t)s] / I32; }, [&](int64_t s) { return cells[(size_t)s] % I32; },
-                         h->U, h->I, h->p_ka.p, h->p_kb.p);
+        const bool flow = !by_levels && h->K <= 256 && !h->force_wide_cells;
+        const int64_t e = h->epoch_cursor;
+        const int xb = (int)(e & 1);
+        CYMF_TRY(relmf_exact_prepare(h, e, flow));     // (made under the previous epoch's kernel, except for a call's first epoch)
+        CYMF_HIP(hipStreamWaitEvent(h->stream, h->ev_x[xb], 0));
+        h->epoch_cursor++;
+        if (flow) {
+            // the epoch's draws in their own order, as ONE dataflow launch (relmf_ticket_kernel): the host only numbers the accesses
             CYMF_TRY(h->ticket.prepare(h->U, h->I, h->device, h->stream));
-            CYMF_TRY(h->ticket.ka.reserve((size_t)N)); CYMF_TRY(h->ticket.kb.reserve((size_t)N));
-            CYMF_HIP(hipMemcpyAsync(h->ticket.ka.p, h->p_ka.p, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-            CYMF_HIP(hipMemcpyAsync(h->ticket.kb.p, h->p_kb.p, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-            launch_relmf_ticket<T>(h->K, h->opt, d, h->d_cells.p, N, h->ticket, h->U, h->d_loss.p, h->stream);
+            launch_relmf_ticket<T>(h->K, h->opt, d, h->x_cells[xb].p, N, h->ticket, h->x_ka[xb].p, h->x_kb[xb].p, h->U, h->d_loss.p, h->stream);
             CYMF_HIP(hipGetLastError());
+            if (next) CYMF_TRY(relmf_exact_prepare(h, e + 1, true));   // the host's share of epoch e + 1, under the kernel of epoch e
             CYMF_TRY(h->ticket.check(h->stream, "relmf exact mode"));
             double loss_t = 0;
             CYMF_HIP(hipMemcpyAsync(&loss_t, h->d_loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1296,9 +1329,7 @@ static int relmf_epoch(cymf_relmf *h, RelStore<T> &st, double *loss_out) {
             if (loss_out) *loss_out = loss_t;
             return 0;
         }
-        h->h_cells.resize((size_t)N);
-        CYMF_HIP(hipMemcpyAsync(h->h_cells.data(), h->d_cells.p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        CYMF_HIP(hipStreamSynchronize(h->stream));
+        h->h_cells.assign(h->p_cells[xb].p, h->p_cells[xb].p + N);
         std::vector<int32_t> su((size_t)N), si((size_t)N);
         for (int64_t s = 0; s < N; ++s) {
             su[s] = (int32_t)(h->h_cells[s] / (uint32_t)h->I);
@@ -1360,6 +1391,12 @@ extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t
     if (h->force_wide_cells) h->step_path = false;
     h->tile_ok = !h->force_wide_cells && mode == CYMF_MODE_THROUGHPUT && dtype == CYMF_F32 && relmf_tile_plan(U, I, K, optimizer, &h->plan) &&
                  !(getenv("CYMF_RELMF_NO_TILES") && getenv("CYMF_RELMF_NO_TILES")[0] == '1');
+    const bool exact_side = mode == CYMF_MODE_EXACT && !h->wide;   // the exact mode draws and schedules the next epoch beside the running one
+    if (!rc && exact_side) {
+        hipError_t e2 = create_side_stream(&h->side_stream);
+        for (int b = 0; b < 2 && e2 == hipSuccess; ++b) e2 = hipEventCreateWithFlags(&h->ev_x[b], hipEventDisableTiming);
+        if (e2 != hipSuccess) rc = fail(CYMF_ERR_HIP, "stream/event creation failed: %s", hipGetErrorString(e2));
+    }
     if (!rc && (h->step_path || h->tile_ok)) {
         hipError_t e2 = create_side_stream(&h->side_stream);
         for (int b = 0; b < 2 && e2 == hipSuccess; ++b) {
@@ -1370,7 +1407,7 @@ extern "C" int cymf_relmf_create(cymf_relmf **out, int32_t U, int32_t I, int32_t
     }
     // relmf.pyx:128; >= 2M cells per epoch: chunked jump-ahead generator (rng.hip), else the one-workgroup walker.
     // The generator lives on the stream that consumes it: the side stream on the step path.
-    if (!rc) rc = h->rng.init(seed, (uint64_t)U * (uint64_t)I, (h->step_path || h->tile_ok) ? h->side_stream : h->stream,
+    if (!rc) rc = h->rng.init(seed, (uint64_t)U * (uint64_t)I, (h->step_path || h->tile_ok || exact_side) ? h->side_stream : h->stream,
                               /*parallel=*/(int64_t)U * I >= (int64_t)2 << 20);
     if (rc) { (void)cymf_relmf_destroy(h); return rc; }
     *out = h;
@@ -1460,7 +1497,8 @@ extern "C" int cymf_relmf_epochs(cymf_relmf *h, int32_t n_epochs, double *loss_o
     CYMF_TRY(use_device(h->device));
     for (int32_t e = 0; e < n_epochs; ++e) {
         double *lo = loss_out ? loss_out + e : nullptr;
-        if (h->dtype == CYMF_F32) CYMF_TRY(relmf_epoch<float>(h, h->f32, lo)); else CYMF_TRY(relmf_epoch<double>(h, h->f64, lo));
+        const bool next = e + 1 < n_epochs;   // (exact mode: the following epoch is prepared under this epoch's kernel)
+        if (h->dtype == CYMF_F32) CYMF_TRY(relmf_epoch<float>(h, h->f32, lo, next)); else CYMF_TRY(relmf_epoch<double>(h, h->f64, lo, next));
     }
     return 0;
 }
@@ -1474,6 +1512,7 @@ extern "C" int cymf_relmf_destroy(cymf_relmf *h) {
     for (int b = 0; b < 2; ++b) {
         if (h->ev_bucketed[b]) (void)hipEventDestroy(h->ev_bucketed[b]);
         if (h->ev_step_done[b]) (void)hipEventDestroy(h->ev_step_done[b]);
+        if (h->ev_x[b]) (void)hipEventDestroy(h->ev_x[b]);
     }
     delete h;
     return 0;
