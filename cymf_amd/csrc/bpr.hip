@@ -1091,16 +1091,68 @@ int exact_prepare(cymf_bpr *h, int64_t e) {
     int32_t *const tu = h->p_tu[b].p, *const ti = h->p_ti[b].p, *const tj = h->p_tj[b].p;
     uint32_t *const ku = h->p_ku[b].p, *const ki = h->p_ki[b].p, *const kj = h->p_kj[b].p;
     int64_t n_perf = 0;
-    for (int64_t l = 0; l < N; ++l) {
-        const int32_t u = h->h_users[l], i = h->h_pos_items[l];
-        const int32_t j = (int32_t)h_draws[h->h_gpos[l]];
-        const bool positive = h->h_pos_bits.empty() ? csr_has(h->h_indptr, h->h_indices, u, j)
-                                                    : (h->h_pos_bits[((size_t)u * h->I + j) >> 6] >> (((size_t)u * h->I + j) & 63)) & 1;
-        if (positive) continue;                                    // bpr.pyx:166-167
-        h->h_last_neg[l] = j;
-        tu[n_perf] = u; ti[n_perf] = i; tj[n_perf] = j;
-        ku[n_perf] = cntW[u]++; ki[n_perf] = cntH[i]++; kj[n_perf] = cntH[j]++;
-        ++n_perf;
+    int T = host_threads(N);
+    if ((int64_t)T * ((int64_t)h->U + h->I) > ((int64_t)64 << 20)) T = (int)std::max<int64_t>(1, ((int64_t)64 << 20) / ((int64_t)h->U + h->I));
+    int32_t *const last_neg = h->h_last_neg.data();
+    const int32_t *const users_l = h->h_users.data(), *const items_l = h->h_pos_items.data();
+    const uint32_t *const gpos = h->h_gpos.data();
+    // the skip test of every triplet (bpr.pyx:166-167: a binary search in the user's positives where U x I is too large for a bitmap) has
+    // no order in it: on a few host threads for large problems -- at 10^7 triplets it was a second per epoch, more than the kernel
+    parallel_chunks(N, T, [&](int, int64_t lb, int64_t le) {
+        for (int64_t l = lb; l < le; ++l) {
+            const int32_t u = users_l[l];
+            const int32_t j = (int32_t)h_draws[gpos[l]];
+            const bool positive = h->h_pos_bits.empty() ? csr_has(h->h_indptr, h->h_indices, u, j)
+                                                        : (h->h_pos_bits[((size_t)u * h->I + j) >> 6] >> (((size_t)u * h->I + j) & 63)) & 1;
+            last_neg[l] = positive ? -1 : j;
+        }
+    });
+    if (T <= 1) {
+        for (int64_t l = 0; l < N; ++l) {
+            const int32_t j = last_neg[l];
+            if (j < 0) continue;
+            const int32_t u = users_l[l], i = items_l[l];
+            tu[n_perf] = u; ti[n_perf] = i; tj[n_perf] = j;
+            ku[n_perf] = cntW[u]++; ki[n_perf] = cntH[i]++; kj[n_perf] = cntH[j]++;
+            ++n_perf;
+        }
+    } else {
+        // the turn numbers are ranks inside each row's accesses in sequential order: per-thread counts of every row over contiguous
+        // chunks of the order, offsets by (row, chunk), then every chunk numbers its own triplets -- the serial numbers exactly
+        const size_t Us = (size_t)h->U, Is = (size_t)h->I;
+        std::vector<uint32_t> cw((size_t)T * Us, 0u), ch((size_t)T * Is, 0u);
+        std::vector<int64_t> first((size_t)T + 1, 0);
+        parallel_chunks(N, T, [&](int t, int64_t lb, int64_t le) {
+            uint32_t *w = cw.data() + (size_t)t * Us, *hh = ch.data() + (size_t)t * Is;
+            int64_t np = 0;
+            for (int64_t l = lb; l < le; ++l) {
+                const int32_t j = last_neg[l];
+                if (j < 0) continue;
+                w[users_l[l]]++; hh[items_l[l]]++; hh[j]++;
+                ++np;
+            }
+            first[(size_t)t + 1] = np;
+        });
+        for (int t = 0; t < T; ++t) first[(size_t)t + 1] += first[(size_t)t];
+        parallel_chunks((int64_t)Us, T, [&](int, int64_t b0, int64_t e0) {
+            for (int64_t r = b0; r < e0; ++r) { uint32_t run = 0; for (int t = 0; t < T; ++t) { uint32_t &c = cw[(size_t)t * Us + (size_t)r]; const uint32_t v = c; c = run; run += v; } }
+        });
+        parallel_chunks((int64_t)Is, T, [&](int, int64_t b0, int64_t e0) {
+            for (int64_t r = b0; r < e0; ++r) { uint32_t run = 0; for (int t = 0; t < T; ++t) { uint32_t &c = ch[(size_t)t * Is + (size_t)r]; const uint32_t v = c; c = run; run += v; } }
+        });
+        parallel_chunks(N, T, [&](int t, int64_t lb, int64_t le) {
+            uint32_t *w = cw.data() + (size_t)t * Us, *hh = ch.data() + (size_t)t * Is;
+            int64_t p = first[(size_t)t];
+            for (int64_t l = lb; l < le; ++l) {
+                const int32_t j = last_neg[l];
+                if (j < 0) continue;
+                const int32_t u = users_l[l], i = items_l[l];
+                tu[p] = u; ti[p] = i; tj[p] = j;
+                ku[p] = w[u]++; ki[p] = hh[i]++; kj[p] = hh[j]++;
+                ++p;
+            }
+        });
+        n_perf = first[(size_t)T];
     }
     const double t_turns = now();
     CYMF_TRY(h->d_xu[b].reserve((size_t)N)); CYMF_TRY(h->d_xi[b].reserve((size_t)N)); CYMF_TRY(h->d_xj[b].reserve((size_t)N));

@@ -475,3 +475,16 @@ def test_layout_built_on_several_host_threads_applies_every_triplet_once():
     err = np.abs(got - pred).max(axis=1)
     assert (err <= 0.05 * ref + 1e-9).mean() > 0.999 and (err <= 0.5 * ref + 1e-9).all()
     assert np.array_equal((W - W0)[users[~ok]], np.zeros(((~ok).sum(), K)))
+
+
+def test_exact_mode_large_epoch_numbered_on_several_host_threads():
+    """From 2^20 triplets up the exact mode's host half -- the skip test of every draw (here a binary search: U x I is beyond the bitmap)
+    and the turn numbering -- runs on several host threads (per-thread counts of every row, offsets by (row, chunk)); two epochs, the
+    second prepared under the first one's kernel.  Against the sequential oracle, float64."""
+    U, I, K = 300_000, 8_000, 8
+    X = synthetic.implicit_matrix(U, I, 1_300_000, 31)
+    assert X.nnz >= (1 << 20) and U * I > (1 << 31)
+    W, H, losses = oracle.bpr_fit(X, K, "adam", 0.002, 0.01, 2)
+    m = _fit(X, K, "adam", 0.002, 0.01, 2, "float64")
+    assert rel_fro(m.W, W) <= 1e-10 and rel_fro(m.H, H) <= 1e-10
+    assert np.allclose(m.losses, losses, rtol=1e-9)
