@@ -1,6 +1,7 @@
 // rng.h -- device-resident negative-sample index stream (bit-exact std::mt19937 + libstdc++-11
 // uniform_int_distribution<long>, i.e. the reference's UniformGenerator, cymf/math.pyx:12-18).
 #pragma once
+#include <vector>
 #include "common.h"
 
 namespace cymf {
@@ -48,6 +49,8 @@ class DeviceRng {
     uint64_t raw_pos_ = 0;              // next unconsumed raw word of the stream
     DevBuf<uint32_t> poly_, states_, tmp_, counts_, rej_, rej_cnt_;
     int64_t states_cap_ = 0, states_known_ = 0;   // chunk start states [0, states_known_) are valid
+    std::vector<uint32_t *> retired_;   // outgrown state tables, freed with the generator: a hipFree is a device-wide synchronisation, and the
+                                        // table is outgrown in the middle of an epoch whose kernel the caller wants to work beside
     struct Pending {
         bool active = false;
         hipEvent_t done = nullptr;

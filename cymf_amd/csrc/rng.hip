@@ -391,6 +391,8 @@ __global__ void widen_u32_i64_kernel(const uint32_t *__restrict__ in, int64_t *_
 }  // namespace
 
 DeviceRng::~DeviceRng() {
+    if (!process_exiting())
+        for (uint32_t *p : retired_) (void)hipFree(p);
     if (pend_.done) (void)hipEventDestroy(pend_.done);
     if (pend_.h_counts) (void)hipHostFree(pend_.h_counts);
     if (pend_.h_rej) (void)hipHostFree(pend_.h_rej);
@@ -450,6 +452,8 @@ int DeviceRng::ensure_states(int64_t last_chunk, hipStream_t s) {
         CYMF_HIP(hipStreamSynchronize(s));
         std::swap(bigger.p, states_.p);
         std::swap(bigger.n, states_.n);
+        retired_.push_back(bigger.p);   // (not freed here: see rng.h)
+        bigger.p = nullptr; bigger.n = 0;
         states_cap_ = cap;
     }
     // Level l jumps by D = 4^l chunks: a run of up to D states follows from the run D chunks before it in ONE launch, one
