@@ -208,8 +208,17 @@ def main():
     W0 = rs.uniform(-0.1, 0.1, size=(U, K)) / K
     H0 = rs.uniform(-0.1, 0.1, size=(I, K)) / K
 
+    # One GPU: the windows are the library's own (what fit() runs: ~2.5 M triplets each, chosen for fidelity to the reference's order,
+    # DESIGN.md 4.1) -- a bench step of ~`batch` triplets is the whole number of them nearest to that choice, so that the K steps
+    # are still whole epochs.  Sharded: a window ends with the exchange, one window per step.
+    windows_per_step = 1
+    if comm is None:
+        probe = BprTrainer(U, I, K, args.optimizer, lr, wd, dtype="float32", mode="throughput", device=device, steps_per_epoch=None)
+        probe.set_data(users, positives, csr_indptr, csr_indices, gpos, nnz)
+        windows_per_step = max(1, int(round(probe.steps_per_epoch() / spe)))
+        probe.close()
     trainer = BprTrainer(U, I, K, args.optimizer, lr, wd, dtype="float32", mode="throughput", device=device,
-                         steps_per_epoch=spe, comm=comm)
+                         steps_per_epoch=spe * windows_per_step, comm=comm)
     t0 = time.time()
     trainer.set_data(users, positives, csr_indptr, csr_indices, gpos, nnz)
     trainer.upload(W0, H0)
@@ -222,14 +231,14 @@ def main():
         if comm is not None:
             comm.barrier()
 
-    trainer.steps(args.warmup)
+    trainer.steps(args.warmup * windows_per_step)
     barrier()
     p_before, _ = trainer.stats()
     trainer.set_profiling(True)
     trainer.kernel_time()            # reset
     barrier()
     t0 = time.perf_counter()
-    trainer.steps(args.steps)
+    trainer.steps(args.steps * windows_per_step)
     barrier()
     elapsed = time.perf_counter() - t0
     p_after, s_after = trainer.stats()
@@ -316,7 +325,7 @@ def main():
             # the reference's DEFAULT optimizer (cymf/bpr.pyx:50) on the headline workload: same data, same steps, same timing
             try:
                 c3_adam = timed_steps(U, I, K, "adam", 0.002, wd, device, spe, users, positives, csr_indptr, csr_indices, nnz, W0, H0,
-                                      args.warmup, args.steps, args.config)
+                                      args.warmup, args.steps, args.config, windows_per_step)
             except Exception as e:   # pragma: no cover
                 c3_adam = {"error": f"{type(e).__name__}: {e}"}
             log(0, f"secondary C3_bpr_adam_k128: {c3_adam.get('value', c3_adam.get('error'))}")
@@ -354,12 +363,16 @@ def main():
             "data": "synthetic",
             "epochs_covered": epochs_covered,
             "mode_note": "lock-free (throughput) mode, the reference's num_threads > 1 regime: statistical parity only.  This headline (step kernel, "
-                         f"{spe} item-bucketed windows of the shuffled order per epoch) is held to a low-concurrency run of the same windowed order at full size "
-                         "(tests/test_gpu_fullsize.py); the small-table lines (C2) to the sequential oracle in the reference's own shuffled order "
-                         "(tests/test_gpu_order_fidelity.py).  W/H parity to 1e-4 is the exact mode's (num_threads == 1), which is not what is timed here: DESIGN.md 4, 4.1",
+                         f"{spe * windows_per_step} item-bucketed windows of the shuffled order per epoch" + (" = fit()'s own choice" if comm is None else "")
+                         + ") is held to the sequential oracle in the reference's own shuffled order at full size -- windows of 2 M triplets: loss -1.6 %, "
+                         "held-out Recall@5 -0.0023 after three epochs, profiles/r03_c3_order_fidelity.md -- and to a low-concurrency run of the same windowed "
+                         "order (tests/test_gpu_fullsize.py); the small-table lines (C2) and ml-20m-shaped data to the oracle as well "
+                         "(tests/test_gpu_order_fidelity.py, test_gpu_fullsize.py).  W/H parity to 1e-4 is the exact mode's (num_threads == 1), which is not what is "
+                         "timed here: DESIGN.md 4, 4.1",
             "config": {"workload": f"{args.config}: {U} users x {I} items, {nnz} interactions, K={K}, "
                                    f"{args.optimizer} lr={lr} wd={wd}, HOGWILD mode",
                        "triplets_per_gpu_per_step": nnz // (spe * world), "steps_per_epoch": spe,
+                       "windows_per_step": windows_per_step, "windows_per_epoch": spe * windows_per_step,
                        "sharding": f"users x{world}" + (", RCCL all-reduce of item deltas per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
@@ -383,22 +396,22 @@ def main():
                       ignore_errors=True)
 
 
-def timed_steps(U, I, K, opt, lr, wd, device, spe, users, positives, indptr, indices, nnz, W0, H0, warmup, steps, config):
+def timed_steps(U, I, K, opt, lr, wd, device, spe, users, positives, indptr, indices, nnz, W0, H0, warmup, steps, config, windows_per_step=1):
     """N = 1: `steps` timed steps of the lock-free step kernel on the headline data with another optimizer -- the headline's own
     timing rule (both streams drained on either side, HIP events on the kernel's stream for the roofline)."""
     bpt = {"sgd": 24, "adagrad": 48, "adam": 72}[opt] * K + 12
-    t = BprTrainer(U, I, K, opt, lr, wd, dtype="float32", mode="throughput", device=device, steps_per_epoch=spe)
+    t = BprTrainer(U, I, K, opt, lr, wd, dtype="float32", mode="throughput", device=device, steps_per_epoch=spe * windows_per_step)
     try:
         t.set_data(users, positives, indptr, indices, None, nnz)
         t.upload(W0, H0)
-        t.steps(warmup)
+        t.steps(warmup * windows_per_step)
         t.sync()
         p0, _ = t.stats()
         t.set_profiling(True)
         t.kernel_time()
         t.sync()
         t0 = time.perf_counter()
-        t.steps(steps)
+        t.steps(steps * windows_per_step)
         t.sync()
         dt = time.perf_counter() - t0
         p1, _ = t.stats()
@@ -406,7 +419,7 @@ def timed_steps(U, I, K, opt, lr, wd, device, spe, users, positives, indptr, ind
     finally:
         t.close()
     a = bpt * (p1 - p0) / max(k_n, 1) / max(k_ms / 1e3 / max(k_n, 1), 1e-12)
-    return {"workload": f"{config}: {U} x {I}, {nnz} interactions, K={K}, {opt} lr={lr} wd={wd}, lock-free mode, {spe} steps per epoch",
+    return {"workload": f"{config}: {U} x {I}, {nnz} interactions, K={K}, {opt} lr={lr} wd={wd}, lock-free mode, {spe} steps of {windows_per_step} window(s) per epoch",
             "value": (p1 - p0) / dt, "unit": "triplet-updates/s", "ms": 1e3 * dt / steps, "kernel_ms": k_ms / max(k_n, 1),
             "roofline": {"bound": "hbm", "achieved": a / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": a / HBM_PEAK, "bytes_per_unit": bpt,
                          "kernel": "bpr_step_kernel", "traffic": None, "timing": "HIP events on the kernel's stream, average launch"}}

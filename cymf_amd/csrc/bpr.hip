@@ -1627,8 +1627,11 @@ bool group_kernel_fits(const cymf_bpr *h);
 //    oracle in the reference's order (tools/order_fidelity.py): runs of 5 858 / 1 464 slots diverge /
 //    cost 7 % of the norm of H, 366 slots 4.5 %, 91 slots 0.6 % -> at most 128 slots of the hottest item per window, at least 16
 //    windows, windows of at least 2 048 slots.
-//  * step kernel (large tables): windows of ~5 M triplets of the global order (the size bench.py's headline runs at: a launch
-//    long enough to fill the chip), the same on every rank of a sharded job; never fewer than four (see below).
+//  * step kernel (large tables): windows of ~2.5 M triplets of the global order (a sharded job: ~5 M, the same on every rank);
+//    never fewer than four (see below).  Measured at C3's full size against the sequential oracle in the reference's order, three
+//    epochs of SGD (profiles/r03_c3_order_fidelity.md): windows of 5 M / 2 M / 1 M triplets end at loss -4.9 / -1.6 / -0.7 %,
+//    held-out Recall@5 -0.0095 / -0.0023 / -0.0009, and cost 0 / 4 / 11 % of the throughput (a window's runs of one item
+//    shorten, H[i] is forwarded less) -- 2.5 M keeps Recall@5 and the loss well inside the bars of DESIGN.md section 4 for 3 %.
 int32_t choose_steps_per_epoch(const cymf_bpr *h, int64_t hottest_item_count) {
     const int64_t n_global = std::max<int64_t>(h->N_global, 1);
     if (group_kernel_fits(h)) {
@@ -1640,7 +1643,9 @@ int32_t choose_steps_per_epoch(const cymf_bpr *h, int64_t hottest_item_count) {
     // ... and at least four of them while a window still holds a quarter of a million triplets: from four windows on the sequential
     // oracle over the bucketed order is indistinguishable from the shuffled order (norm of H 93.1 against 95.3; one
     // window: 72.8)
-    int64_t S = std::max<int64_t>(4, std::min<int64_t>(4096, (n_global + 2500000) / 5000000));
+    // (a sharded job: a window ends with the exchange of the item deltas -- few, large ones)
+    const int64_t win = h->comm ? 5000000 : 2500000;
+    int64_t S = std::max<int64_t>(4, std::min<int64_t>(4096, (n_global + win / 2) / win));
     while (S > 1 && n_global / S < 262144) S /= 2;
     return (int32_t)S;
 }
