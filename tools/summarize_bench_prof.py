@@ -147,7 +147,13 @@ tj_path = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 tj = {k: v for k, v in tj.items() if not k.endswith("_phases")}     # one set of per-kernel aggregates: the newest
 tj[f"{tag}_phases"] = traffic
-tj["bench"] = dict(flat, source=f"profiles/{tag}_bench_kernels.md", c3_slots_per_launch=5000000)
+c3_slots = 5000000   # slots per launch of the step kernel in the profiled run: its bench line says (a step may be several windows)
+try:
+    cfg = json.load(open(os.path.join(root, "bench_plain.json")))["config"]
+    c3_slots = int(cfg["triplets_per_gpu_per_step"]) // int(cfg.get("windows_per_step", 1))
+except Exception:
+    pass
+tj["bench"] = dict(flat, source=f"profiles/{tag}_bench_kernels.md", c3_slots_per_launch=c3_slots)
 for stale in ("glove_step_C5_K100", "relmf_step_20000x8000_K64", "_source_secondary"):   # round-1 figures of kernels that no longer exist
     tj.pop(stale, None)
 tj[f"{tag}_source"] = f"profiles/{tag}_bench_kernels.md (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over the driver's bench command)"
